@@ -1,0 +1,108 @@
+/*
+ * libqlinear - MI355X (gfx950) quantized-linear kernels behind a plain C ABI.
+ *
+ * Every entry point replaces one piece of the reference's Python/Triton quantized-linear path
+ * (citations are file:line in the reference checkout, nanovllm/utils/quantization.py unless a
+ * file is named).  Conventions:
+ *   - all pointers are DEVICE pointers owned by the caller; matrices are row-major and dense;
+ *   - bf16 = 16-bit brain float bit patterns, fp8 = OCP e4m3fn bit patterns, scales = float32;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); nothing here
+ *     synchronises the host, allocates or frees device memory, so every call may be captured into
+ *     a hipGraph;
+ *   - return value 0 = launched; a negative QL_E* code = rejected before any launch, with a
+ *     message available from ql_last_error() (thread-local).  The reference asserts instead.
+ */
+#ifndef QLINEAR_H
+#define QLINEAR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* storage type of quantized values: torch.int8 / torch.float8_e4m3fn (quantization.py:151) */
+#define QL_INT8 0
+#define QL_FP8 1
+
+/* granularity of the weight scales */
+#define QL_PER_ROW 0    /* sw[N]            (QLinear,       :349-364) */
+#define QL_PER_TENSOR 1 /* sw[1]            (QTensorLinear, :367-382) */
+#define QL_PER_GROUP 2  /* sw[N, K/group]   (QGroupLinear,  :385-401) */
+
+#define QL_OK 0
+#define QL_EINVAL (-1)      /* bad enum / null pointer / negative size */
+#define QL_ESHAPE (-2)      /* shape not supported by the kernels (K % 32, group size, ...) */
+#define QL_EWORKSPACE (-3)  /* workspace too small */
+#define QL_ELAUNCH (-4)     /* HIP reported a launch error */
+
+int ql_version(void);
+const char* ql_last_error(void);
+
+/* ---- quantizers ------------------------------------------------------------------------- */
+
+/* per_row_quant + _per_row_quant_kernel (:13-51, :147-163).  x[T,H] bf16 -> q[T,H] (1 byte each),
+ * scale[T] f32.  row_max = max(max|x|,1e-8); scale = row_max/Q; q = cast(x * (Q/row_max)) with
+ * roundf (half away from zero) for int8 and RTNE for fp8; Q = 127 | 448.  Used on weights at
+ * conversion time and on activations at every W8A8 forward.  Requires H % 8 == 0. */
+int ql_quant_per_row(int dtype, const void* x_bf16, int64_t T, int64_t H, void* q, float* scale,
+                     void* stream);
+
+/* per_tensor_quant (:166-191).  One scale for the whole [N,K] bf16 tensor; amax, scale and x/scale
+ * are rounded to bf16 as the reference's bf16 tensor arithmetic does; int8 uses round-half-even +
+ * clamp(-128,127).  `scale` receives the (bf16-valued) scale as f32.  `workspace` >= 16 bytes. */
+int ql_quant_per_tensor(int dtype, const void* w_bf16, int64_t N, int64_t K, void* q, float* scale,
+                        void* workspace, void* stream);
+
+/* per_group_quant (:194-234).  scales[N, K/group] f32 = max(amax_group,1e-8)/Q; q = x/scale with
+ * round-half-even + clamp (int8) or RTNE cast (fp8).  Requires group % 8 == 0, group <= 512,
+ * 512 % group == 0 and K % group == 0. */
+int ql_quant_per_group(int dtype, const void* w_bf16, int64_t N, int64_t K, int group, void* q,
+                       float* scales, void* stream);
+
+/* _fake_per_block_quant (:404-431) and its wrappers (:434-445): quantize-dequantize, bf16 in,
+ * bf16 out (out may alias w).  granularity QL_PER_TENSOR (blocks -1,-1), QL_PER_ROW (1,-1) or
+ * QL_PER_GROUP (1,group).  `workspace` >= 16 bytes (used by QL_PER_TENSOR only). */
+int ql_fake_quant(int dtype, int granularity, const void* w_bf16, int64_t N, int64_t K, int group,
+                  void* out_bf16, void* workspace, void* stream);
+
+/* ---- fused dequant GEMMs ---------------------------------------------------------------- */
+
+/* Bytes of scratch the GEMM entry points need for an [M,N,K] problem with the configuration the
+ * library would pick right now (split-K partial slabs; 0 when K is not split).  `granularity` is
+ * the value that will be passed to ql_gemm_w8a16 (use QL_PER_ROW for ql_gemm_w8a8). */
+size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity);
+
+/* Weight-only forward: y[M,N] bf16 = x[M,K] bf16 . dequant(qw[N,K])^T (+ bias[N] bf16).
+ *   QL_PER_ROW    y = bf16( (sum_k x*q) * sw[n] + bias )                 - the W8A16 counterpart of
+ *                 QLinear; numerics of F.linear(x, fake_per_row_quant(W)) (:438-439) without the
+ *                 extra bf16 rounding of the dequantised weight.
+ *   QL_PER_TENSOR y = bf16( bf16(sum_k x*(q*sw)) + bias )                - per_tensor_matmul (:237-262)
+ *   QL_PER_GROUP  y = bf16( bf16(sum_g sw[n,g] * sum_{k in g} x*q) + bias ) - per_group_matmul (:265-307)
+ * int8/fp8 weights are widened to bf16 in registers (exact) and contracted on bf16 MFMA with f32
+ * accumulation; nothing is dequantised to memory.  Requires K % 32 == 0; per-group additionally
+ * (group % 128 == 0) or (128 % group == 0 and group >= 32), and K % group == 0. */
+int ql_gemm_w8a16(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
+                  const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* _per_row_post_process_mm as launched by per_row_matmul (:54-144, :324-345):
+ * y[M,N] bf16 = bf16( (sum_k qx[m,k]*qw[n,k]) * sx[m] * sw[n] + bias[n] ), both operands int8
+ * (exact int32 accumulation on i8 MFMA) or both fp8-e4m3fn (f32 accumulation on fp8 MFMA).
+ * The bias is added per output column (the reference's kernel indexes it by tile row, :133).
+ * Requires K % 32 == 0. */
+int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
+                 const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Tuning hook for benchmarks/tests: force the tile configuration of the next GEMM calls made by
+ * this thread.  mt = 32-row fragments per wave (1,2,4,8), wn x wk = how the block's 4 waves split
+ * N and K ((4,1),(2,2),(1,4)), split_k = K slices across workgroups.  Any argument <= 0 restores
+ * the built-in heuristic for that field.  Returns QL_EINVAL for a combination that is not built. */
+int ql_gemm_force_config(int mt, int wn, int wk, int split_k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLINEAR_H */

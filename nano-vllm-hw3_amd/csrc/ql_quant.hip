@@ -1,0 +1,312 @@
+// Quantizer kernels: per-row (dynamic, also used on activations), per-group, per-tensor and the
+// quantize-dequantize ("fake") forms.  All are HBM-bound byte movers: 16-byte loads per lane,
+// one pass for the row/group maxima and one for the conversion (the second pass hits L2).
+#include "ql_common.h"
+
+namespace ql {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <int DT> struct QMax;
+template <> struct QMax<QL_INT8> { static constexpr float v = 127.f; };
+template <> struct QMax<QL_FP8> { static constexpr float v = 448.f; };
+
+__device__ __forceinline__ float absmax8(const u16x8& v) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(bf16_bits_to_f32(v[j])));
+    return m;
+}
+
+// max over the 256 threads of a block (4 waves)
+__device__ __forceinline__ float block_max_256(float v, float* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return v;
+}
+
+// ---- per-row: one 256-thread block per row ---------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void quant_per_row_kernel(const unsigned short* __restrict__ x,
+                                                            unsigned char* __restrict__ q,
+                                                            float* __restrict__ scale, int64_t H) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const unsigned short* xr = x + row * H;
+    float m = 0.f;
+    for (int64_t c = threadIdx.x * 8; c < H; c += 256 * 8) m = fmaxf(m, absmax8(*(const u16x8*)(xr + c)));
+    m = block_max_256(m, sh);
+    const float row_max = fmaxf(m, 1e-8f);
+    const float sc = row_max / QMax<DT>::v;
+    const float sc_inv = QMax<DT>::v / row_max;
+    if (threadIdx.x == 0) scale[row] = sc;
+    unsigned char* qr = q + row * H;
+    for (int64_t c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        const u16x8 v = *(const u16x8*)(xr + c);
+        unsigned long long out = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = bf16_bits_to_f32(v[j]) * sc_inv;
+            unsigned b;
+            if (DT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)roundf(y);
+            else b = f32_to_e4m3fn(y);
+            out |= (unsigned long long)b << (8 * j);
+        }
+        *(unsigned long long*)(qr + c) = out;
+    }
+}
+
+// ---- per-group: g/8 adjacent lanes share a group ------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void quant_per_group_kernel(const unsigned short* __restrict__ x,
+                                                              unsigned char* __restrict__ q,
+                                                              float* __restrict__ scales, int64_t total,
+                                                              int group) {
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const bool live = e < total;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) v = *(const u16x8*)(x + e);
+    float m = absmax8(v);
+    const int lanes = group >> 3;
+    for (int o = 1; o < lanes; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float sc = fmaxf(m, 1e-8f) / QMax<DT>::v;
+    if (!live) return;
+    if ((threadIdx.x & (lanes - 1)) == 0) scales[e / group] = sc;
+    unsigned long long out = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float y = bf16_bits_to_f32(v[j]) / sc;
+        unsigned b;
+        if (DT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)fminf(fmaxf(rintf(y), -128.f), 127.f);
+        else b = f32_to_e4m3fn(y);
+        out |= (unsigned long long)b << (8 * j);
+    }
+    *(unsigned long long*)(q + e) = out;
+}
+
+// ---- per-tensor: global |max| via atomicMax on the (non-negative) f32 bit pattern ---------------
+__global__ __launch_bounds__(256) void absmax_kernel(const unsigned short* __restrict__ x, int64_t total,
+                                                     unsigned* __restrict__ ws) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < total; e += (int64_t)gridDim.x * 256 * 8)
+        m = fmaxf(m, absmax8(*(const u16x8*)(x + e)));
+    m = block_max_256(m, sh);
+    if (threadIdx.x == 0) atomicMax(ws, __builtin_bit_cast(unsigned, m));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void quant_per_tensor_kernel(const unsigned short* __restrict__ x,
+                                                               unsigned char* __restrict__ q,
+                                                               float* __restrict__ scale_out,
+                                                               const unsigned* __restrict__ ws, int64_t total) {
+    // amax, scale and x/scale are bf16 tensors in the reference: round each to bf16
+    const float amax = fmaxf(__builtin_bit_cast(float, ws[0]), round_to_bf16(1e-8f));
+    const float sc = round_to_bf16(amax / QMax<DT>::v);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = sc;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < total; e += (int64_t)gridDim.x * 256 * 8) {
+        const u16x8 v = *(const u16x8*)(x + e);
+        unsigned long long out = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = round_to_bf16(bf16_bits_to_f32(v[j]) / sc);
+            unsigned b;
+            if (DT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)fminf(fmaxf(rintf(y), -128.f), 127.f);
+            else b = f32_to_e4m3fn(y);
+            out |= (unsigned long long)b << (8 * j);
+        }
+        *(unsigned long long*)(q + e) = out;
+    }
+}
+
+// ---- fake quant: quantize-dequantize one value given its block's amax (bf16-valued) -----------
+template <int DT>
+__device__ __forceinline__ unsigned short fake_one(float x, float amax) {
+    float y;
+    if (DT == QL_INT8) {
+        const float step = round_to_bf16(amax / 127.f);   // bf16 tensor / int stays bf16
+        const float t = (x / amax) * 127.f;
+        y = rintf(t) * step;
+    } else {
+        const float t = (x / amax) * 448.f;
+        const float d = e4m3fn_to_f32(f32_to_e4m3fn(t));
+        y = (d / 448.f) * amax;
+    }
+    return f32_to_bf16_bits(y);
+}
+
+template <int DT>
+__device__ __forceinline__ void fake8(const u16x8& v, float amax, unsigned short* out) {
+    u16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fake_one<DT>(bf16_bits_to_f32(v[j]), amax);
+    *(u16x8*)out = o;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void fake_per_row_kernel(const unsigned short* __restrict__ x,
+                                                           unsigned short* __restrict__ out, int64_t H) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const unsigned short* xr = x + row * H;
+    float m = 0.f;
+    for (int64_t c = threadIdx.x * 8; c < H; c += 256 * 8) m = fmaxf(m, absmax8(*(const u16x8*)(xr + c)));
+    m = fmaxf(block_max_256(m, sh), round_to_bf16(1e-8f));
+    for (int64_t c = threadIdx.x * 8; c < H; c += 256 * 8) fake8<DT>(*(const u16x8*)(xr + c), m, out + row * H + c);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void fake_per_group_kernel(const unsigned short* __restrict__ x,
+                                                             unsigned short* __restrict__ out, int64_t total,
+                                                             int group) {
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const bool live = e < total;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) v = *(const u16x8*)(x + e);
+    float m = absmax8(v);
+    const int lanes = group >> 3;
+    for (int o = 1; o < lanes; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    m = fmaxf(m, round_to_bf16(1e-8f));
+    if (live) fake8<DT>(v, m, out + e);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void fake_per_tensor_kernel(const unsigned short* __restrict__ x,
+                                                              unsigned short* __restrict__ out,
+                                                              const unsigned* __restrict__ ws, int64_t total) {
+    const float amax = fmaxf(__builtin_bit_cast(float, ws[0]), round_to_bf16(1e-8f));
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < total; e += (int64_t)gridDim.x * 256 * 8)
+        fake8<DT>(*(const u16x8*)(x + e), amax, out + e);
+}
+
+static bool group_ok(int g) { return g >= 8 && g <= 512 && (g % 8) == 0 && (512 % g) == 0; }
+static int stream_grid(int64_t total) {
+    int64_t b = (total / 8 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace ql
+
+using namespace ql;
+
+extern "C" {
+
+int ql_version(void) { return 1; }
+const char* ql_last_error(void) { return ql::g_err; }
+
+int ql_quant_per_row(int dtype, const void* x, int64_t T, int64_t H, void* q, float* scale, void* stream) {
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || (T > 0 && (!x || !q || !scale)) || T < 0 || H <= 0) {
+        set_error("ql_quant_per_row: bad argument (dtype=%d T=%lld H=%lld)", dtype, (long long)T, (long long)H);
+        return QL_EINVAL;
+    }
+    if (H % 8) { set_error("ql_quant_per_row: H=%lld must be a multiple of 8", (long long)H); return QL_ESHAPE; }
+    if (T == 0) return QL_OK;
+    if (T > 0x7FFFFFFF) { set_error("ql_quant_per_row: T too large"); return QL_ESHAPE; }
+    dim3 grid((unsigned)T), block(256);
+    if (dtype == QL_INT8)
+        hipLaunchKernelGGL(quant_per_row_kernel<QL_INT8>, grid, block, 0, as_stream(stream),
+                           (const unsigned short*)x, (unsigned char*)q, scale, H);
+    else
+        hipLaunchKernelGGL(quant_per_row_kernel<QL_FP8>, grid, block, 0, as_stream(stream),
+                           (const unsigned short*)x, (unsigned char*)q, scale, H);
+    QL_CHECK_LAUNCH("ql_quant_per_row");
+    return QL_OK;
+}
+
+int ql_quant_per_group(int dtype, const void* w, int64_t N, int64_t K, int group, void* q, float* scales,
+                       void* stream) {
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || !w || !q || !scales || N < 0 || K <= 0) {
+        set_error("ql_quant_per_group: bad argument");
+        return QL_EINVAL;
+    }
+    if (!group_ok(group) || K % group) {
+        set_error("ql_quant_per_group: K=%lld, group=%d unsupported (need group|512, group%%8==0, K%%group==0)",
+                  (long long)K, group);
+        return QL_ESHAPE;
+    }
+    const int64_t total = N * K;
+    if (total == 0) return QL_OK;
+    const int64_t blocks = (total / 8 + 255) / 256;
+    if (blocks > 0x7FFFFFFF) { set_error("ql_quant_per_group: tensor too large"); return QL_ESHAPE; }
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == QL_INT8)
+        hipLaunchKernelGGL(quant_per_group_kernel<QL_INT8>, grid, block, 0, as_stream(stream),
+                           (const unsigned short*)w, (unsigned char*)q, scales, total, group);
+    else
+        hipLaunchKernelGGL(quant_per_group_kernel<QL_FP8>, grid, block, 0, as_stream(stream),
+                           (const unsigned short*)w, (unsigned char*)q, scales, total, group);
+    QL_CHECK_LAUNCH("ql_quant_per_group");
+    return QL_OK;
+}
+
+int ql_quant_per_tensor(int dtype, const void* w, int64_t N, int64_t K, void* q, float* scale, void* workspace,
+                        void* stream) {
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || !w || !q || !scale || !workspace || N <= 0 || K <= 0) {
+        set_error("ql_quant_per_tensor: bad argument");
+        return QL_EINVAL;
+    }
+    const int64_t total = N * K;
+    if (total % 8) { set_error("ql_quant_per_tensor: N*K must be a multiple of 8"); return QL_ESHAPE; }
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) { set_error("ql_quant_per_tensor: memset failed"); return QL_ELAUNCH; }
+    dim3 grid(stream_grid(total)), block(256);
+    hipLaunchKernelGGL(absmax_kernel, grid, block, 0, s, (const unsigned short*)w, total, (unsigned*)workspace);
+    if (dtype == QL_INT8)
+        hipLaunchKernelGGL(quant_per_tensor_kernel<QL_INT8>, grid, block, 0, s, (const unsigned short*)w,
+                           (unsigned char*)q, scale, (const unsigned*)workspace, total);
+    else
+        hipLaunchKernelGGL(quant_per_tensor_kernel<QL_FP8>, grid, block, 0, s, (const unsigned short*)w,
+                           (unsigned char*)q, scale, (const unsigned*)workspace, total);
+    QL_CHECK_LAUNCH("ql_quant_per_tensor");
+    return QL_OK;
+}
+
+int ql_fake_quant(int dtype, int granularity, const void* w, int64_t N, int64_t K, int group, void* out,
+                  void* workspace, void* stream) {
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || !w || !out || N <= 0 || K <= 0) {
+        set_error("ql_fake_quant: bad argument");
+        return QL_EINVAL;
+    }
+    if (K % 8) { set_error("ql_fake_quant: K must be a multiple of 8"); return QL_ESHAPE; }
+    hipStream_t s = as_stream(stream);
+    const int64_t total = N * K;
+    const unsigned short* x = (const unsigned short*)w;
+    unsigned short* o = (unsigned short*)out;
+    if (granularity == QL_PER_ROW) {
+        if (N > 0x7FFFFFFF) { set_error("ql_fake_quant: N too large"); return QL_ESHAPE; }
+        dim3 grid((unsigned)N), block(256);
+        if (dtype == QL_INT8) hipLaunchKernelGGL(fake_per_row_kernel<QL_INT8>, grid, block, 0, s, x, o, K);
+        else hipLaunchKernelGGL(fake_per_row_kernel<QL_FP8>, grid, block, 0, s, x, o, K);
+    } else if (granularity == QL_PER_GROUP) {
+        if (!group_ok(group) || K % group) { set_error("ql_fake_quant: group=%d unsupported for K=%lld", group, (long long)K); return QL_ESHAPE; }
+        const int64_t blocks = (total / 8 + 255) / 256;
+        if (blocks > 0x7FFFFFFF) { set_error("ql_fake_quant: tensor too large"); return QL_ESHAPE; }
+        dim3 grid((unsigned)blocks), block(256);
+        if (dtype == QL_INT8) hipLaunchKernelGGL(fake_per_group_kernel<QL_INT8>, grid, block, 0, s, x, o, total, group);
+        else hipLaunchKernelGGL(fake_per_group_kernel<QL_FP8>, grid, block, 0, s, x, o, total, group);
+    } else if (granularity == QL_PER_TENSOR) {
+        if (!workspace) { set_error("ql_fake_quant: per-tensor needs a workspace"); return QL_EINVAL; }
+        if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) { set_error("ql_fake_quant: memset failed"); return QL_ELAUNCH; }
+        dim3 grid(stream_grid(total)), block(256);
+        hipLaunchKernelGGL(absmax_kernel, grid, block, 0, s, x, total, (unsigned*)workspace);
+        if (dtype == QL_INT8) hipLaunchKernelGGL(fake_per_tensor_kernel<QL_INT8>, grid, block, 0, s, x, o, (const unsigned*)workspace, total);
+        else hipLaunchKernelGGL(fake_per_tensor_kernel<QL_FP8>, grid, block, 0, s, x, o, (const unsigned*)workspace, total);
+    } else {
+        set_error("ql_fake_quant: unknown granularity %d", granularity);
+        return QL_EINVAL;
+    }
+    QL_CHECK_LAUNCH("ql_fake_quant");
+    return QL_OK;
+}
+
+}  // extern "C"

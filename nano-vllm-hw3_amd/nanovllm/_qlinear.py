@@ -1,0 +1,113 @@
+"""ctypes binding of libqlinear.so (the C ABI declared in include/qlinear.h).
+
+There is no CPU fallback: if the shared library is missing, or an op is asked to run on a tensor
+that is not a contiguous CUDA tensor of the expected dtype, this module raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libqlinear.so")
+
+QL_INT8, QL_FP8 = 0, 1
+QL_PER_ROW, QL_PER_TENSOR, QL_PER_GROUP = 0, 1, 2
+
+_c_vp, _c_i64, _c_int, _c_sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every function of include/qlinear.h
+SIGNATURES = {
+    "ql_version": (_c_int, []),
+    "ql_last_error": (ctypes.c_char_p, []),
+    "ql_quant_per_row": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp]),
+    "ql_quant_per_tensor": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "ql_quant_per_group": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),
+    "ql_fake_quant": (_c_int, [_c_int, _c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),
+    "ql_gemm_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_int]),
+    "ql_gemm_w8a16": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
+                               _c_int, _c_vp, _c_sz, _c_vp]),
+    "ql_gemm_w8a8": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
+                              _c_vp, _c_sz, _c_vp]),
+    "ql_gemm_force_config": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+}
+
+_lib = None
+
+
+class QLinearError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libqlinear.so and type its entry points.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QLinearError(
+            f"{LIB_PATH} not found: build it with `python nano-vllm-hw3_amd/build.py` "
+            "(or __graft_entry__.build()); there is no CPU fallback for the quantized-linear path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise QLinearError(f"libqlinear error {rc}: {load().ql_last_error().decode()}")
+
+
+def dtype_code(dtype):
+    if dtype == torch.int8:
+        return QL_INT8
+    if dtype == torch.float8_e4m3fn:
+        return QL_FP8
+    raise AssertionError(f"quantized dtype must be torch.int8 or torch.float8_e4m3fn, got {dtype}")
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t, dtype, name):
+    if not t.is_cuda:
+        raise QLinearError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise QLinearError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise QLinearError(f"{name} must be contiguous")
+    return t
+
+
+class _Workspace:
+    """One growable scratch buffer per device for split-K slabs.  It is sized outside graph capture
+    (reserve()); during capture a too-small workspace is an error instead of a hidden allocation."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def reserve(self, device, nbytes):
+        device = torch.device(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        cur = self.buf.get(key)
+        if cur is None or cur.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise QLinearError(
+                    f"split-K workspace of {nbytes} bytes requested during graph capture; call "
+                    "reserve_workspace() for the largest batch before capturing")
+            self.buf[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        return self.buf[key]
+
+    def get(self, device, nbytes):
+        if nbytes == 0:
+            return None, 0
+        b = self.reserve(device, nbytes)
+        return b.data_ptr(), b.numel()
+
+
+workspace = _Workspace()

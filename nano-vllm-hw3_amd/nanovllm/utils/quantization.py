@@ -1,0 +1,363 @@
+"""Quantized linear layers on MI355X: the host-side mirror of the reference's
+``nanovllm/utils/quantization.py`` (same function / class names, argument meaning and assertions),
+with every tensor operation executed by hand-written HIP kernels behind ``libqlinear.so``.
+
+Differences from the reference, all deliberate:
+  * the modules are tensor-parallel aware (the reference asserts ``tp_size == 1``,
+    quantization.py:360, 378, 397): column-parallel shards keep their own rows' scales,
+    row-parallel shards quantize their K-shard and all-reduce the partial outputs exactly as
+    ``RowParallelLinear.forward`` does (linear.py:149-153);
+  * ``QLinear`` can run weight-only (``weight_only=True``: bf16 activations, W8A16) besides the
+    reference's dynamic-activation W8A8 form;
+  * per-tensor / per-group forwards fuse the dequant into the MFMA GEMM instead of materialising an
+    fp32 copy of the weight per call (quantization.py:258-259, 299-302);
+  * the bias is added per output column (the reference's Triton kernel indexes it by tile row,
+    quantization.py:133).
+"""
+import torch
+import torch.distributed as dist
+
+from nanovllm import _qlinear as Q
+
+_DTYPES = [torch.float8_e4m3fn, torch.int8]
+
+
+def _ws16(device):
+    return Q.workspace.reserve(device, 16)
+
+
+# --------------------------------------------------------------------------- quantizers
+@torch.no_grad()
+def per_row_quant(x: torch.Tensor, dtype: torch.dtype):
+    """x [T, H] bf16 -> (q [T, H] dtype, scale [T] f32).  Reference: quantization.py:147-163."""
+    assert dtype in _DTYPES
+    assert x.dim() == 2
+    Q.require_cuda(x, torch.bfloat16, "x")
+    T, H = x.shape
+    qx = torch.empty_like(x, dtype=dtype)
+    sx = torch.empty((T,), dtype=torch.float32, device=x.device)
+    Q.check(Q.load().ql_quant_per_row(Q.dtype_code(dtype), x.data_ptr(), T, H, qx.data_ptr(), sx.data_ptr(),
+                                      Q.stream_ptr(x.device)))
+    return qx, sx
+
+
+@torch.no_grad()
+def per_tensor_quant(x: torch.Tensor, dtype: torch.dtype):
+    """One scale for the whole tensor; the scale comes back as a 0-dim tensor of x's dtype, as in the
+    reference (quantization.py:166-191)."""
+    assert dtype in _DTYPES
+    Q.require_cuda(x, torch.bfloat16, "x")
+    x2 = x.reshape(-1, x.shape[-1])
+    qx = torch.empty_like(x, dtype=dtype)
+    scale = torch.empty((1,), dtype=torch.float32, device=x.device)
+    Q.check(Q.load().ql_quant_per_tensor(Q.dtype_code(dtype), x2.data_ptr(), x2.shape[0], x2.shape[1], qx.data_ptr(),
+                                         scale.data_ptr(), _ws16(x.device).data_ptr(), Q.stream_ptr(x.device)))
+    return qx, scale[0].to(x.dtype)
+
+
+@torch.no_grad()
+def per_group_quant(x: torch.Tensor, group_size: int, dtype: torch.dtype):
+    """Groups of ``group_size`` along K; scales [N, K/group] f32.  Reference: quantization.py:194-234."""
+    assert dtype in _DTYPES
+    assert x.dim() == 2
+    assert x.size(1) % group_size == 0, f"K dim ({x.size(1)}) must be divisible by group_size ({group_size})"
+    Q.require_cuda(x, torch.bfloat16, "x")
+    N, K = x.shape
+    qx = torch.empty_like(x, dtype=dtype)
+    sx = torch.empty((N, K // group_size), dtype=torch.float32, device=x.device)
+    Q.check(Q.load().ql_quant_per_group(Q.dtype_code(dtype), x.data_ptr(), N, K, group_size, qx.data_ptr(),
+                                        sx.data_ptr(), Q.stream_ptr(x.device)))
+    return qx, sx
+
+
+# --------------------------------------------------------------------------- matmuls
+def _flatten(x, n_out):
+    y_shape = list(x.shape)[:-1] + [n_out]
+    return x.reshape(-1, x.shape[-1]), y_shape
+
+
+def _w8a16(x, qw, sw, bias, granularity, group_size, dtype):
+    assert dtype in _DTYPES and qw.dtype == dtype
+    x2, y_shape = _flatten(x, qw.shape[0])
+    Q.require_cuda(x2, torch.bfloat16, "x")
+    Q.require_cuda(qw, dtype, "qw")
+    sw32 = sw if sw.dtype == torch.float32 else sw.to(torch.float32)
+    sw32 = Q.require_cuda(sw32.reshape(-1) if sw32.dim() == 0 else sw32, torch.float32, "sw")
+    if bias is not None:
+        Q.require_cuda(bias, torch.bfloat16, "bias")
+    M, K = x2.shape
+    N = qw.shape[0]
+    assert qw.shape[1] == K, f"x has K={K} but qw has K={qw.shape[1]}"
+    lib = Q.load()
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    ws_ptr, ws_len = Q.workspace.get(x.device, lib.ql_gemm_workspace_bytes(M, N, K, granularity))
+    Q.check(lib.ql_gemm_w8a16(Q.dtype_code(dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
+                              bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
+                              group_size or 0, ws_ptr, ws_len, Q.stream_ptr(x.device)))
+    return y.view(y_shape)
+
+
+@torch.no_grad()
+def per_tensor_matmul(x, qw, sw, bias, dtype):
+    """``(x.float() @ (qw.float() * sw).T).to(bf16) + bias`` fused (quantization.py:237-262)."""
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_TENSOR, 0, dtype)
+
+
+@torch.no_grad()
+def per_group_matmul(x, qw, sw, bias, group_size, dtype):
+    """Per-group dequant fused into the GEMM (quantization.py:265-307)."""
+    assert qw.shape[1] % group_size == 0
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_GROUP, group_size, dtype)
+
+
+@torch.no_grad()
+def per_row_weight_only_matmul(x, qw, sw, bias, dtype):
+    """W8A16 with per-output-channel scales: ``bf16((x @ q.T) * sw + bias)``; the numerics the
+    reference reaches through ``F.linear(x, fake_per_row_quant(W))`` (quantization.py:438-439)."""
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_ROW, 0, dtype)
+
+
+@torch.no_grad()
+def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None):
+    """The dual-scale GEMM on already-quantized activations (quantization.py:54-144, 331-345)."""
+    assert dtype in _DTYPES
+    Q.require_cuda(qx, dtype, "qx")
+    Q.require_cuda(qw, dtype, "qw")
+    Q.require_cuda(sx, torch.float32, "sx")
+    Q.require_cuda(sw, torch.float32, "sw")
+    if bias is not None:
+        Q.require_cuda(bias, torch.bfloat16, "bias")
+    M, K = qx.shape
+    N = qw.shape[0]
+    assert qw.shape[1] == K
+    lib = Q.load()
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=qx.device)
+    ws_ptr, ws_len = Q.workspace.get(qx.device, lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW))
+    Q.check(lib.ql_gemm_w8a8(Q.dtype_code(dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
+                             bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K, ws_ptr, ws_len,
+                             Q.stream_ptr(qx.device)))
+    return y if y_shape is None else y.view(y_shape)
+
+
+@torch.no_grad()
+def per_row_matmul(x, qw, sw, bias, dtype):
+    """Dynamic per-token activation quant + W8A8 GEMM (quantization.py:310-346)."""
+    x2, y_shape = _flatten(x, qw.size(0))
+    assert x2.size(1) % 32 == 0, f"K({x2.size(1)}) must be multiple of 32"
+    qx, sx = per_row_quant(x2.contiguous(), dtype)
+    return w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape)
+
+
+def reserve_workspace(max_tokens: int, shapes, device=None):
+    """Size the split-K scratch for every [N, K] in ``shapes`` and every graph-captured batch up to
+    ``max_tokens`` (call before hipGraph capture: nothing may allocate inside a capture)."""
+    lib = Q.load()
+    device = device if device is not None else torch.cuda.current_device()
+    need = 0
+    ms = sorted(set([1, 2, 4, 8] + list(range(16, max(max_tokens, 16) + 1, 16)) + [max_tokens]))
+    for (N, K) in shapes:
+        for M in ms:
+            for gran in (Q.QL_PER_ROW, Q.QL_PER_GROUP):
+                need = max(need, lib.ql_gemm_workspace_bytes(M, N, K, gran))
+    Q.workspace.reserve(device, need)
+    return need
+
+
+# --------------------------------------------------------------------------- modules
+def _tp_info(other):
+    return getattr(other, "tp_dim", None), getattr(other, "tp_rank", 0), getattr(other, "tp_size", 1)
+
+
+class _QBase(torch.nn.Module):
+    """Shared TP behaviour: a module converted from a row-parallel linear (tp_dim == 1) adds the bias
+    on rank 0 only and sums the partial outputs over the TP group (linear.py:149-153)."""
+
+    def _init_tp(self, tp_dim=None, tp_rank=0, tp_size=1):
+        self.tp_dim, self.tp_rank, self.tp_size = tp_dim, tp_rank, tp_size
+
+    def _bias_for_rank(self):
+        if self.tp_dim == 1 and self.tp_rank != 0:
+            return None
+        return self.bias
+
+    def _finish(self, y):
+        if self.tp_dim == 1 and self.tp_size > 1:
+            from nanovllm.layers.linear import tp_all_reduce
+            y = tp_all_reduce(y)
+        return y
+
+
+class QLinear(_QBase):
+    """Per-row quantized Linear layer (reference: quantization.py:349-364).  ``weight_only=False`` is
+    the reference's W8A8 form; ``weight_only=True`` keeps activations in bf16 (W8A16)."""
+
+    def __init__(self, dtype, weight: torch.Tensor, bias, weight_only: bool = False):
+        super().__init__()
+        assert dtype in _DTYPES
+        self.dtype = dtype
+        self.weight_only = weight_only
+        self.qw, self.sw = per_row_quant(weight.contiguous(), dtype)
+        self.bias = bias
+        self._init_tp()
+
+    @classmethod
+    def from_linear(cls, other, dtype, weight_only: bool = False):
+        m = cls(dtype, other.weight.data, other.bias, weight_only)
+        m._init_tp(*_tp_info(other))
+        return m
+
+    def forward(self, x: torch.Tensor):
+        fn = per_row_weight_only_matmul if self.weight_only else per_row_matmul
+        return self._finish(fn(x, self.qw, self.sw, self._bias_for_rank(), self.dtype))
+
+
+class QTensorLinear(_QBase):
+    """Per-tensor quantized Linear layer (reference: quantization.py:367-382)."""
+
+    def __init__(self, dtype, weight: torch.Tensor, bias):
+        super().__init__()
+        assert dtype in _DTYPES
+        self.dtype = dtype
+        self.qw, self.sw = per_tensor_quant(weight.contiguous(), dtype)
+        self._sw32 = self.sw.to(torch.float32).reshape(1)
+        self.bias = bias
+        self._init_tp()
+
+    @classmethod
+    def from_linear(cls, other, dtype):
+        m = cls(dtype, other.weight.data, other.bias)
+        m._init_tp(*_tp_info(other))
+        return m
+
+    def forward(self, x: torch.Tensor):
+        return self._finish(per_tensor_matmul(x, self.qw, self._sw32, self._bias_for_rank(), self.dtype))
+
+
+class QGroupLinear(_QBase):
+    """Per-group quantized Linear layer (reference: quantization.py:385-401)."""
+
+    def __init__(self, dtype, weight: torch.Tensor, bias, group_size: int):
+        super().__init__()
+        assert dtype in _DTYPES
+        self.dtype = dtype
+        self.group_size = group_size
+        self.qw, self.sw = per_group_quant(weight.contiguous(), group_size, dtype)
+        self.bias = bias
+        self._init_tp()
+
+    @classmethod
+    def from_linear(cls, other, dtype, group_size: int):
+        m = cls(dtype, other.weight.data, other.bias, group_size)
+        m._init_tp(*_tp_info(other))
+        return m
+
+    def forward(self, x: torch.Tensor):
+        return self._finish(per_group_matmul(x, self.qw, self.sw, self._bias_for_rank(), self.group_size, self.dtype))
+
+
+# --------------------------------------------------------------------------- fake quant
+@torch.no_grad()
+def _fake_per_block_quant(x: torch.Tensor, blk_m: int, blk_n: int, dtype: torch.dtype):
+    """Quantize-dequantize in bf16 (reference: quantization.py:404-431).  Supported block shapes are
+    the ones the reference's wrappers use: (-1,-1) per tensor, (1,-1) per row, (1,g) per group."""
+    assert dtype in _DTYPES
+    Q.require_cuda(x, torch.bfloat16, "x")
+    x2 = x.reshape(-1, x.size(-1))
+    m, n = x2.shape
+    if blk_m == -1 and blk_n == -1:
+        gran, g = Q.QL_PER_TENSOR, 0
+    elif blk_m == 1 and (blk_n == -1 or blk_n == n):
+        gran, g = Q.QL_PER_ROW, 0
+    elif blk_m == 1:
+        assert n % blk_n == 0, f"n({n}) must be multiple of blk_n({blk_n})"
+        gran, g = Q.QL_PER_GROUP, blk_n
+    else:
+        raise AssertionError(f"block shape ({blk_m},{blk_n}) is not one of per-tensor / per-row / per-group")
+    out = torch.empty_like(x2)
+    Q.check(Q.load().ql_fake_quant(Q.dtype_code(dtype), gran, x2.data_ptr(), m, n, g, out.data_ptr(),
+                                   _ws16(x.device).data_ptr(), Q.stream_ptr(x.device)))
+    return out.reshape(x.shape)
+
+
+def fake_per_tensor_quant(x, dtype):
+    return _fake_per_block_quant(x, -1, -1, dtype)
+
+
+def fake_per_row_quant(x, dtype):
+    return _fake_per_block_quant(x, 1, -1, dtype)
+
+
+def fake_per_group_quant(x, group_size, dtype):
+    return _fake_per_block_quant(x, 1, group_size, dtype)
+
+
+# --------------------------------------------------------------------------- model rewriters
+def _layers(model):
+    return model.model.layers
+
+
+def _empty_cache():
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def apply_weight_fake_quant(model, weight_fake_quant_fn=lambda x: x):
+    """Overwrite the four linear weights of every decoder layer with fn(weight) (quantization.py:448-460)."""
+    for l in _layers(model):
+        for mod in (l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj):
+            mod.weight.data = weight_fake_quant_fn(mod.weight.data)
+
+
+apply_weight_quant = apply_weight_fake_quant   # quantization.py:499-513 is the same walk
+
+
+def _replace(model, make):
+    for l in _layers(model):
+        l.self_attn.qkv_proj = make(l.self_attn.qkv_proj)
+        l.self_attn.o_proj = make(l.self_attn.o_proj)
+        l.mlp.gate_up_proj = make(l.mlp.gate_up_proj)
+        l.mlp.down_proj = make(l.mlp.down_proj)
+    _empty_cache()
+
+
+def apply_per_row_quant(model, dtype, weight_only: bool = False):
+    """Replace the four linears per layer by QLinear (quantization.py:463-472)."""
+    _replace(model, lambda lin: QLinear.from_linear(lin, dtype, weight_only))
+
+
+def apply_tensor_quant(model, dtype):
+    """quantization.py:475-484"""
+    _replace(model, lambda lin: QTensorLinear.from_linear(lin, dtype))
+
+
+def apply_group_quant(model, dtype, group_size: int):
+    """quantization.py:487-496"""
+    _replace(model, lambda lin: QGroupLinear.from_linear(lin, dtype, group_size))
+
+
+def apply_quant_torchao(model, linear_dtype=torch.float8_e4m3fn):
+    """The reference hands the model to torchao here (quantization.py:516-524).  torchao is a
+    third-party package outside this build; selecting it is an error rather than a silent no-op."""
+    raise NotImplementedError("quant_type='smoothquant' delegates to torchao, which is not part of this build")
+
+
+def apply_quant_from_config(model, config):
+    """The dispatch of ModelRunner.__init__ (model_runner.py:36-57): weight_quant_fn wins, then
+    quant_type, then a non-bf16 linear_dtype means per-row.  ``per_row_weight_only`` (alias
+    ``w8a16``) is this build's addition: per-row scales with bf16 activations."""
+    if getattr(config, "weight_quant_fn", None) is not None:
+        apply_weight_fake_quant(model, config.weight_quant_fn)
+    elif getattr(config, "quant_type", None) is not None:
+        qt = config.quant_type
+        if qt == "per_tensor":
+            apply_tensor_quant(model, config.linear_dtype)
+        elif qt == "per_row":
+            apply_per_row_quant(model, config.linear_dtype)
+        elif qt in ("per_row_weight_only", "w8a16"):
+            apply_per_row_quant(model, config.linear_dtype, weight_only=True)
+        elif qt == "per_group":
+            apply_group_quant(model, config.linear_dtype, config.group_size)
+        elif qt == "smoothquant":
+            apply_quant_torchao(model, config.linear_dtype)
+    elif config.linear_dtype != torch.bfloat16:
+        apply_per_row_quant(model, config.linear_dtype)

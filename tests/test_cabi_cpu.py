@@ -1,0 +1,69 @@
+"""CPU-side checks of the C ABI: the built library loads, exports every function the header
+declares (no compute is called here), and the Python binding types all of them."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "qlinear.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ql_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    for must in ("ql_quant_per_row", "ql_quant_per_tensor", "ql_quant_per_group", "ql_fake_quant",
+                 "ql_gemm_w8a16", "ql_gemm_w8a8", "ql_gemm_workspace_bytes", "ql_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from nanovllm import _qlinear as Q
+    assert os.path.exists(Q.LIB_PATH), "build libqlinear.so first: python nano-vllm-hw3_amd/build.py"
+    lib = ctypes.CDLL(Q.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in qlinear.h but not exported"
+
+
+def test_binding_covers_header():
+    from nanovllm import _qlinear as Q
+    assert sorted(Q.SIGNATURES) == declared_functions()
+    lib = Q.load()
+    assert lib.ql_version() >= 1
+
+
+def test_argument_validation_needs_no_gpu():
+    """Rejections happen before any HIP call, so they can be exercised on a CPU-only host."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    one = ctypes.c_void_p(16)   # never dereferenced: the calls below are rejected first
+    assert lib.ql_gemm_w8a16(7, 0, one, one, one, None, one, 4, 64, 128, 0, None, 0, None) == -1
+    assert b"bad argument" in lib.ql_last_error()
+    assert lib.ql_gemm_w8a16(0, 0, one, one, one, None, one, 4, 64, 100, 0, None, 0, None) == -2
+    assert b"multiple of 32" in lib.ql_last_error()
+    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 256, 96, None, 0, None) == -2
+    assert lib.ql_quant_per_group(0, one, 4, 256, 96, one, one, None) == -2
+    assert lib.ql_quant_per_row(0, one, 4, 100, one, one, None) == -2
+    assert lib.ql_gemm_w8a8(0, one, one, one, None, None, one, 4, 64, 128, None, 0, None) == -1
+    assert lib.ql_gemm_force_config(3, 4, 1, 0) == -1
+    assert lib.ql_gemm_force_config(0, 0, 0, 0) == 0
+    # workspace sizing is pure host arithmetic
+    assert lib.ql_gemm_workspace_bytes(256, 4096, 1024, 0) == 0 or lib.ql_gemm_workspace_bytes(256, 4096, 1024, 0) % (256 * 4096 * 4) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    """No silent CPU fallback: the operator layer raises on non-GPU tensors."""
+    import torch
+    from nanovllm import _qlinear as Q
+    from nanovllm.utils import quantization as NQ
+    x = torch.zeros(4, 128, dtype=torch.bfloat16)
+    with pytest.raises(Q.QLinearError):
+        NQ.per_row_quant(x, torch.int8)
+    with pytest.raises(Q.QLinearError):
+        NQ.per_group_quant(x, 64, torch.int8)

@@ -1,0 +1,315 @@
+"""GPU parity: the HIP library (through its C ABI) against the numpy oracle and the committed golden
+vectors.  Integer/byte results (quantizers, int8 GEMM) must be bit-exact; floating-point GEMMs must
+sit within half a bf16 ulp of the exactly-evaluated reference formula plus an explicit
+f32-accumulation allowance (see tests/util.py::assert_gemm_close)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qlinear_oracle as O
+from tests.util import TDT, assert_gemm_close, bf16_t, bits8, bits16, q_t, rand_bf16
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["m1_n64_k128", "m3_n64_k256", "m16_n48_k512", "m130_n64_k256", "m5_n8_k3072"]
+DTYPES = ["int8", "fp8"]
+
+
+@pytest.fixture(scope="module")
+def NQ():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from nanovllm.utils import quantization as NQ
+    from nanovllm import _qlinear as Q
+    Q.load()
+    return NQ
+
+
+# ----------------------------------------------------------------------------- quantizers
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dt", DTYPES)
+def test_quantizers_match_golden_bit_exact(NQ, golden, case, dt):
+    w = bf16_t(golden[f"{case}/w"])
+    q, s = NQ.per_tensor_quant(w, TDT[dt])
+    assert np.array_equal(bits8(q), golden[f"{case}/{dt}/tensor/qw"])
+    assert float(s.float()) == golden[f"{case}/{dt}/tensor/sw"][0]
+    assert s.dtype == torch.bfloat16 and s.dim() == 0
+    for g in (64, 128):
+        q, s = NQ.per_group_quant(w, g, TDT[dt])
+        assert np.array_equal(bits8(q), golden[f"{case}/{dt}/g{g}/qw"])
+        assert np.array_equal(s.cpu().numpy(), golden[f"{case}/{dt}/g{g}/sw"])
+
+
+@pytest.mark.parametrize("case", CASES[:2])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_fake_quant_matches_golden_bit_exact(NQ, golden, case, dt):
+    w = bf16_t(golden[f"{case}/w"])
+    assert np.array_equal(bits16(NQ.fake_per_row_quant(w, TDT[dt])), golden[f"{case}/{dt}/fake_row/w"])
+    assert np.array_equal(bits16(NQ.fake_per_tensor_quant(w, TDT[dt])), golden[f"{case}/{dt}/fake_tensor/w"])
+    assert np.array_equal(bits16(NQ.fake_per_group_quant(w, 128, TDT[dt])), golden[f"{case}/{dt}/fake_g128/w"])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 8), (5, 136), (256, 1024), (130, 3072), (1, 16384), (33, 2048)])
+def test_per_row_quant_bit_exact_vs_oracle(NQ, dt, shape):
+    rng = np.random.default_rng(hash((dt, shape)) % 2 ** 31)
+    x = rand_bf16(rng, shape, std=rng.choice([0.02, 1.0, 30.0]))
+    x[0, :] = 0                          # all-zero row: amax floor 1e-8
+    if shape[0] > 2:
+        x[2, : shape[1] // 2] = x[2, 0]  # many equal values / ties on the grid
+    q, s = NQ.per_row_quant(bf16_t(x), TDT[dt])
+    qo, so = O.per_row_quant(x, dt)
+    assert np.array_equal(s.cpu().numpy(), so)
+    assert np.array_equal(bits8(q), qo.view(np.uint8))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_group_and_tensor_quant_bit_exact_vs_oracle_large(NQ, dt):
+    rng = np.random.default_rng(5)
+    w = rand_bf16(rng, (1024, 3072), std=0.02)
+    w[3, 256:384] = 0
+    for g in (32, 64, 128, 256, 512):
+        q, s = NQ.per_group_quant(bf16_t(w), g, TDT[dt])
+        qo, so = O.per_group_quant(w, g, dt)
+        assert np.array_equal(s.cpu().numpy(), so), g
+        assert np.array_equal(bits8(q), qo.view(np.uint8)), g
+    q, s = NQ.per_tensor_quant(bf16_t(w), TDT[dt])
+    qo, so = O.per_tensor_quant(w, dt)
+    assert s.float().item() == np.float32(so).item()
+    assert np.array_equal(bits8(q), qo.view(np.uint8))
+    for fn_g, fn_o in ((lambda t: NQ.fake_per_row_quant(t, TDT[dt]), lambda a: O.fake_per_row_quant(a, dt)),
+                       (lambda t: NQ.fake_per_group_quant(t, 128, TDT[dt]), lambda a: O.fake_per_group_quant(a, 128, dt)),
+                       (lambda t: NQ.fake_per_tensor_quant(t, TDT[dt]), lambda a: O.fake_per_tensor_quant(a, dt))):
+        assert np.array_equal(bits16(fn_g(bf16_t(w))), fn_o(w))
+
+
+# ----------------------------------------------------------------------------- W8A16 GEMMs
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dt", DTYPES)
+def test_w8a16_group_and_tensor_match_golden(NQ, golden, case, dt):
+    """per_group_matmul / per_tensor_matmul on the reference's own quantized weights and outputs."""
+    xb, bb = golden[f"{case}/x"], golden[f"{case}/b"]
+    x, b = bf16_t(xb), bf16_t(bb)
+    for g in (64, 128):
+        qw, sw = golden[f"{case}/{dt}/g{g}/qw"], golden[f"{case}/{dt}/g{g}/sw"]
+        deq = (O._decode_q(qw, dt).reshape(qw.shape[0], -1, g) * sw[..., None]).reshape(qw.shape)
+        l1 = O.abs_product_sum(xb, deq)
+        y = NQ.per_group_matmul(x, q_t(qw, dt), torch.from_numpy(sw).cuda(), None, g, TDT[dt])
+        assert_gemm_close(bits16(y), O.per_group_matmul(xb, qw, sw, None, g, dt, return_f64=True), l1, what=f"g{g}")
+        # and directly against the reference's bf16 output: both are roundings of the same number
+        ref = O.bf16_to_f32(golden[f"{case}/{dt}/g{g}/y"]).astype(np.float64)
+        assert_gemm_close(bits16(y), ref, l1, double_round=True, what=f"g{g} vs golden")
+        yb = NQ.per_group_matmul(x, q_t(qw, dt), torch.from_numpy(sw).cuda(), b, g, TDT[dt])
+        refb = O.bf16_to_f32(golden[f"{case}/{dt}/g{g}/y_bias"]).astype(np.float64)
+        assert_gemm_close(bits16(yb), refb, l1 + np.abs(O.bf16_to_f32(bb))[None, :], double_round=True, what="bias")
+    qw, sw = golden[f"{case}/{dt}/tensor/qw"], golden[f"{case}/{dt}/tensor/sw"]
+    l1 = O.abs_product_sum(xb, O._decode_q(qw, dt) * sw[0])
+    y = NQ.per_tensor_matmul(x, q_t(qw, dt), torch.tensor(sw[0], dtype=torch.bfloat16).cuda(), None, TDT[dt])
+    assert_gemm_close(bits16(y), O.per_tensor_matmul(xb, qw, sw[0], None, dt, return_f64=True), l1, what="tensor")
+    ref = O.bf16_to_f32(golden[f"{case}/{dt}/tensor/y"]).astype(np.float64)
+    assert_gemm_close(bits16(y), ref, l1, double_round=True, what="tensor vs golden")
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dt", DTYPES)
+def test_w8a16_per_row_vs_oracle_and_fake_route(NQ, golden, case, dt):
+    xb, wb = golden[f"{case}/x"], golden[f"{case}/w"]
+    qw, sw = NQ.per_row_quant(bf16_t(wb), TDT[dt])
+    qo, so = O.per_row_quant(wb, dt)
+    assert np.array_equal(bits8(qw), qo.view(np.uint8)) and np.array_equal(sw.cpu().numpy(), so)
+    y = NQ.per_row_weight_only_matmul(bf16_t(xb), qw, sw, None, TDT[dt])
+    deq = O._decode_q(qo, dt) * so[:, None]
+    assert_gemm_close(bits16(y), O.w8a16_rowscale_matmul(xb, qo, so, None, dt, return_f64=True),
+                      O.abs_product_sum(xb, deq), what="per-row W8A16")
+    # against the reference's fake-per-row forward: same tolerance the reference's self-test uses,
+    # tightened 4x (max|d| / max|ref| < 0.02; reference asserts 0.08, quantization.py:549-553)
+    ref = O.bf16_to_f32(golden[f"{case}/{dt}/fake_row/y"])
+    got = O.bf16_to_f32(bits16(y))
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 0.02
+
+
+# ----------------------------------------------------------------------------- W8A8 GEMMs
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mnk", [(1, 64, 128), (3, 96, 256), (16, 48, 512), (130, 256, 1024), (256, 160, 3072),
+                                 (77, 1024, 2048)])
+def test_w8a8_vs_oracle(NQ, dt, mnk):
+    M, N, K = mnk
+    rng = np.random.default_rng(M * 7 + N)
+    xb, wb, bb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05), rand_bf16(rng, (N,))
+    qw, sw = NQ.per_row_quant(bf16_t(wb), TDT[dt])
+    qwo, swo = O.per_row_quant(wb, dt)
+    for bias in (None, bb):
+        y = NQ.per_row_matmul(bf16_t(xb), qw, sw, None if bias is None else bf16_t(bias), TDT[dt])
+        yo = O.per_row_matmul(xb, qwo, swo, bias, dt)
+        if dt == "int8":
+            assert np.array_equal(bits16(y), yo), "int8 W8A8 must be bit-exact (exact int32 accumulation)"
+        else:
+            qx, sx = O.per_row_quant(xb, dt)
+            acc = O.w8a8_gemm(qx, sx, qwo, swo, None, dt, return_acc=True)
+            ref = acc * sx[:, None].astype(np.float64) * swo[None, :].astype(np.float64)
+            l1 = (np.abs(O.fp8_to_f32(qx)).astype(np.float64) @ np.abs(O.fp8_to_f32(qwo)).astype(np.float64).T) \
+                * sx[:, None] * swo[None, :]
+            if bias is not None:
+                ref = ref + O.bf16_to_f32(bias)[None, :]
+                l1 = l1 + np.abs(O.bf16_to_f32(bias))[None, :]
+            assert_gemm_close(bits16(y), ref, l1, what="fp8 W8A8")
+            assert (bits16(y) == yo).mean() > 0.98
+
+
+def test_w8a8_reference_selftest_tolerance(NQ):
+    """The reference's own acceptance test (quantization.py:527-555): randn operands,
+    max|y - (x@w.T+b)| / max|.| < 0.08 for both dtypes."""
+    torch.manual_seed(0)
+    for (M, N, K) in [(1, 1536, 1536), (10, 1536, 1536), (512, 4096, 4096)]:
+        for dt in (torch.int8, torch.float8_e4m3fn):
+            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
+            b = torch.randn(N, device="cuda", dtype=torch.bfloat16)
+            qw, sw = NQ.per_row_quant(w, dt)
+            y = NQ.per_row_matmul(x, qw, sw, b, dt)
+            y_ref = x.float() @ w.float().T + b.float()[None, :]
+            err = (y.float() - y_ref).abs().max() / y_ref.abs().max()
+            assert err < 0.08, (M, N, K, dt, float(err))
+
+
+# ----------------------------------------------------------------------------- every tile / split
+TILES = [(1, 1, 4), (2, 1, 4), (1, 4, 1), (2, 4, 1), (4, 4, 1), (8, 4, 1), (2, 2, 2), (4, 2, 2)]
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("split", [1, 3])
+def test_every_tile_configuration(NQ, tile, split):
+    """Force each built tile (and a split-K that leaves a ragged last slice) on a shape with M, N
+    tails; all four arithmetic variants must still match the oracle."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    M, N, K = 70, 200, 1184          # K = 9.25 * 128: ragged chunks and slices
+    rng = np.random.default_rng(11)
+    xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05)
+    x = bf16_t(xb)
+    Q.workspace.reserve("cuda", 8 * M * N * 4)
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], split) == 0
+        for dt in DTYPES:
+            qo, so = O.per_row_quant(wb, dt)
+            qw, sw = q_t(qo, dt), torch.from_numpy(so).cuda()
+            y = NQ.per_row_weight_only_matmul(x, qw, sw, None, TDT[dt])
+            assert_gemm_close(bits16(y), O.w8a16_rowscale_matmul(xb, qo, so, None, dt, return_f64=True),
+                              O.abs_product_sum(xb, O._decode_q(qo, dt) * so[:, None]), what=f"w8a16 {dt} {tile}")
+            y8 = NQ.per_row_matmul(x, qw, sw, None, TDT[dt])
+            yo = O.per_row_matmul(xb, qo, so, None, dt)
+            if dt == "int8":
+                assert np.array_equal(bits16(y8), yo), f"w8a8 int8 {tile} split {split}"
+            else:
+                assert (bits16(y8) == yo).mean() > 0.98
+            if tile[0] <= 4:
+                g = 32 if dt == "int8" else 64
+                qg, sg = O.per_group_quant(wb[:, :1152], g, dt)
+                yg = NQ.per_group_matmul(bf16_t(xb[:, :1152]), q_t(qg, dt), torch.from_numpy(sg).cuda(), None, g, TDT[dt])
+                deq = (O._decode_q(qg, dt).reshape(N, -1, g) * sg[..., None]).reshape(N, -1)
+                assert_gemm_close(bits16(yg), O.per_group_matmul(xb[:, :1152], qg, sg, None, g, dt, return_f64=True),
+                                  O.abs_product_sum(xb[:, :1152], deq), what=f"group {dt} {tile}")
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("g", [32, 64, 128, 256, 512])
+def test_group_sizes(NQ, g):
+    M, N, K = 40, 96, 1024
+    rng = np.random.default_rng(g)
+    xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05)
+    for dt in DTYPES:
+        qg, sg = O.per_group_quant(wb, g, dt)
+        y = NQ.per_group_matmul(bf16_t(xb), q_t(qg, dt), torch.from_numpy(sg).cuda(), None, g, TDT[dt])
+        deq = (O._decode_q(qg, dt).reshape(N, -1, g) * sg[..., None]).reshape(N, -1)
+        assert_gemm_close(bits16(y), O.per_group_matmul(xb, qg, sg, None, g, dt, return_f64=True),
+                          O.abs_product_sum(xb, deq), what=f"g{g} {dt}")
+
+
+# ----------------------------------------------------------------------------- edge cases / API behaviour
+def test_empty_and_leading_dims(NQ):
+    w = torch.randn(64, 128, device="cuda", dtype=torch.bfloat16)
+    qw, sw = NQ.per_row_quant(w, torch.int8)
+    y = NQ.per_row_weight_only_matmul(torch.empty(0, 128, device="cuda", dtype=torch.bfloat16), qw, sw, None, torch.int8)
+    assert y.shape == (0, 64)
+    x3 = torch.randn(1, 5, 128, device="cuda", dtype=torch.bfloat16)     # the PPL harness feeds [1, T, K]
+    for fn in (NQ.per_row_weight_only_matmul, NQ.per_row_matmul):
+        y3 = fn(x3, qw, sw, None, torch.int8)
+        assert y3.shape == (1, 5, 64) and y3.dtype == torch.bfloat16
+        assert torch.equal(y3[0], fn(x3[0], qw, sw, None, torch.int8))
+
+
+def test_errors_are_loud(NQ):
+    from nanovllm import _qlinear as Q
+    w = torch.randn(64, 96, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(AssertionError):
+        NQ.per_group_quant(w, 64, torch.int8)          # K % group != 0 (reference asserts too)
+    with pytest.raises(AssertionError):
+        NQ.per_row_quant(w, torch.float16)
+    with pytest.raises(Q.QLinearError):
+        NQ.per_row_quant(w.float(), torch.int8)        # only bf16 inputs are implemented
+    w104 = torch.randn(64, 104, device="cuda", dtype=torch.bfloat16)
+    qw, sw = NQ.per_row_quant(w104, torch.int8)
+    with pytest.raises(Q.QLinearError):                # K = 104 is not a multiple of 32
+        NQ.per_row_weight_only_matmul(torch.randn(2, 104, device="cuda", dtype=torch.bfloat16), qw, sw, None, torch.int8)
+
+
+def test_module_classes_match_golden(NQ, golden):
+    """QGroupLinear / QTensorLinear built by from_linear on the same weights the reference used."""
+    from nanovllm.layers.linear import ReplicatedLinear
+    lin = ReplicatedLinear(256, 64)
+    lin.weight.data = bf16_t(golden["module/w"])
+    x = bf16_t(golden["module/x"])
+    l1 = O.abs_product_sum(golden["module/x"], O.bf16_to_f32(golden["module/w"]))
+    y = NQ.QGroupLinear.from_linear(lin, torch.int8, 128)(x)
+    assert_gemm_close(bits16(y), O.bf16_to_f32(golden["module/qgroup_int8_g128/y"]).astype(np.float64), l1, True)
+    y = NQ.QTensorLinear.from_linear(lin, torch.float8_e4m3fn)(x)
+    assert_gemm_close(bits16(y), O.bf16_to_f32(golden["module/qtensor_fp8/y"]).astype(np.float64), l1, True)
+    y8 = NQ.QLinear.from_linear(lin, torch.int8)(x)
+    q, s = O.per_row_quant(golden["module/w"], "int8")
+    assert np.array_equal(bits16(y8), O.per_row_matmul(golden["module/x"], q, s, None, "int8"))
+
+
+# ----------------------------------------------------------------------------- full-size properties
+QWEN3_06B = [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072)]
+
+
+@pytest.mark.parametrize("nk", QWEN3_06B)
+@pytest.mark.parametrize("M", [1, 16, 130, 256, 2048])
+def test_full_size_properties(NQ, nk, M):
+    """At the real Qwen3-0.6B layer shapes the oracle is too slow to run everywhere, so check
+    size-independent properties: (1) int8 W8A8 equals an exact integer GEMM done by torch in int32 on
+    the GPU... replaced by float64 on a row/column sample; (2) the result does not depend on M-tiling
+    (row i of a batch == the same row run alone); (3) a one-hot activation row returns the weight
+    column scaled exactly; (4) determinism."""
+    N, K = nk
+    g = torch.Generator(device="cuda").manual_seed(N + K + M)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    qw, sw = NQ.per_row_quant(w, torch.int8)
+    y = NQ.per_row_weight_only_matmul(x, qw, sw, None, torch.int8)
+    y_again = NQ.per_row_weight_only_matmul(x, qw, sw, None, torch.int8)
+    assert torch.equal(y, y_again), "not deterministic"
+    # (2) batch invariance up to f32 summation order (different M pick different tiles / split-K)
+    rows = sorted(set([0, M // 2, M - 1]))
+    for r in rows:
+        y1 = NQ.per_row_weight_only_matmul(x[r:r + 1].contiguous(), qw, sw, None, torch.int8)
+        d = (y1[0].float() - y[r].float()).abs()
+        assert (d <= y[r].float().abs() * 2.0 ** -7 + 1e-3).all()
+    # (1) sampled rows against float64 on the CPU oracle formula
+    xs = bits16(x[rows])
+    ref = O.w8a16_rowscale_matmul(xs, bits8(qw), sw.cpu().numpy(), None, "int8", return_f64=True)
+    l1 = O.abs_product_sum(xs, O._decode_q(bits8(qw), "int8") * sw.cpu().numpy()[:, None])
+    assert_gemm_close(bits16(y[rows]), ref, l1, what=f"sampled rows {nk} M={M}")
+    # (3) one-hot row: y[0, n] == bf16(q[n, j] * sw[n]) exactly
+    j = K // 3
+    e = torch.zeros(1, K, device="cuda", dtype=torch.bfloat16)
+    e[0, j] = 1.0
+    yh = NQ.per_row_weight_only_matmul(e, qw, sw, None, torch.int8)
+    expect = (qw[:, j].float() * sw).to(torch.bfloat16)
+    assert torch.equal(yh[0], expect)
+    # W8A8 int8: exact against integer arithmetic on sampled rows
+    y8 = NQ.per_row_matmul(x, qw, sw, None, torch.int8)
+    yo = O.per_row_matmul(xs, bits8(qw), sw.cpu().numpy(), None, "int8")
+    assert np.array_equal(bits16(y8[rows]), yo)

@@ -1,0 +1,47 @@
+"""Helpers shared by the tests: torch <-> bit-pattern numpy views and the f32-accumulation tolerance."""
+import numpy as np
+import torch
+
+from oracle import qlinear_oracle as O
+
+TDT = {"int8": torch.int8, "fp8": torch.float8_e4m3fn}
+
+
+def bf16_t(bits, device="cuda"):
+    """uint16 bit patterns -> torch bf16 tensor"""
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16).to(device)
+
+
+def q_t(bits, dt, device="cuda"):
+    """uint8/int8 storage -> torch int8 / float8_e4m3fn tensor"""
+    u = torch.from_numpy(np.ascontiguousarray(bits).view(np.uint8))
+    return (u.view(torch.int8) if dt == "int8" else u.view(torch.float8_e4m3fn)).to(device)
+
+
+def bits16(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def bits8(t):
+    t = t.detach().cpu().contiguous()
+    return (t.view(torch.uint8) if t.dtype != torch.int8 else t.view(torch.uint8)).numpy()
+
+
+def rand_bf16(rng, shape, std=1.0):
+    return O.f32_to_bf16((rng.standard_normal(shape) * std).astype(np.float32))
+
+
+def assert_gemm_close(y_bits, ref64, l1, double_round=False, what=""):
+    """Kernel output (bf16 of an f32-accumulated sum, order unspecified) against the exact value.
+    Tolerance per element: half a bf16 ulp of the result (relative 2**-8; twice that when the
+    reference rounds twice, i.e. bf16(bf16(v)+bias)) plus an f32 accumulation term 2**-18 * L1 where
+    L1 = sum_k |x*w| (worst-case f32 summation error is K * 2**-24 * L1; K <= 16384 here)."""
+    got = O.bf16_to_f32(y_bits).astype(np.float64)
+    rel = (2.0 ** -7 if double_round else 2.0 ** -8) * 1.002
+    tol = rel * np.abs(ref64) + 2.0 ** -18 * l1 + 1e-30
+    bad = np.abs(got - ref64) > tol
+    if bad.any():
+        i = np.argwhere(bad)[0]
+        raise AssertionError(
+            f"{what}: {bad.sum()}/{bad.size} outside tolerance; first at {tuple(i)}: got {got[tuple(i)]!r} "
+            f"ref {ref64[tuple(i)]!r} tol {tol[tuple(i)]!r}")
