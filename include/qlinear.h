@@ -102,6 +102,37 @@ int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, con
  * the built-in heuristic for that field.  Returns QL_EINVAL for a combination that is not built. */
 int ql_gemm_force_config(int mt, int wn, int wk, int split_k);
 
+/* ---- operators between the quantized GEMMs of a decoder layer (one launch each) ------------- */
+
+/* RMSNorm.rms_forward / add_rms_forward (nanovllm/layers/layernorm.py:16-40): with `residual`,
+ * s = x + residual in f32, residual_out = bf16(s); out = bf16( bf16(s * rsqrt(mean(s^2)+eps)) * w ).
+ * residual may be NULL (plain norm; residual_out ignored).  H % 8 == 0, H <= 8192. */
+int ql_add_rmsnorm(const void* x_bf16, const void* residual_bf16, const void* weight_bf16, float eps,
+                   void* out_bf16, void* residual_out_bf16, int64_t T, int64_t H, void* stream);
+
+/* SiluAndMul.forward (nanovllm/layers/activation.py:11-14): out[T,I] = silu(x[:, :I]) * x[:, I:]. */
+int ql_silu_mul(const void* x_bf16, void* out_bf16, int64_t T, int64_t I, void* stream);
+
+/* The q/k path of Qwen3Attention.forward between qkv_proj and attention
+ * (nanovllm/models/qwen3.py:81-88, layers/rotary_embedding.py:7-48, layers/attention.py:10-40):
+ * split qkv[T, (Hq+2Hkv)*128], per-head RMSNorm of q and k (weights may be NULL = no norm),
+ * rotate-half RoPE from cos_sin[pos, 0:64 | 64:128] (f32), q -> q_out[T,Hq,128]; k, v -> k_out/v_out
+ * (optional, contiguous, for prefill attention) and scattered to k_cache/v_cache at row
+ * slot_mapping[t] (skipped for -1 or a NULL slot_mapping).  head_dim must be 128. */
+int ql_qknorm_rope_store(const void* qkv_bf16, const int64_t* positions, const float* cos_sin,
+                         const void* q_norm_w, const void* k_norm_w, float eps, void* q_out, void* k_out,
+                         void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int64_t T,
+                         int Hq, int Hkv, int head_dim, void* stream);
+
+/* Single-query attention over a paged KV cache: the decode half of Attention.forward
+ * (nanovllm/layers/attention.py:59-75, flash_attn_with_kvcache there).  q/out [B,Hq,128];
+ * caches [num_blocks, block_size, Hkv, 128]; block_tables [B, max_blocks]; context_lens [B]
+ * (0 = padded row, output 0).  Hq/Hkv in {1,2,4}. */
+int ql_paged_attn_decode(const void* q_bf16, const void* k_cache, const void* v_cache,
+                         const int* block_tables, const int* context_lens, void* out_bf16, float scale,
+                         int64_t B, int Hq, int Hkv, int head_dim, int block_size, int max_blocks,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

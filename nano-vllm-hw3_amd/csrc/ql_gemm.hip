@@ -383,13 +383,13 @@ struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; };
 
 static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     Plan pl;
-    // rows per block: the smallest tile that covers M, up to 256 rows (128 with group accumulators)
-    const int max_mt = group ? 4 : 8;
-    int mt = 1;
-    while (mt < max_mt && 32 * mt < M) mt *= 2;
-    int wn, wk;
-    if (mt <= 2) { wn = 1; wk = 4; }          // few rows: all four waves stream K of one 32-column strip
-    else { wn = 4; wk = 1; }
+    // Decode-sized problems (M <= 256) are latency/L2-bound, not MFMA-bound, on a 256-CU chip: the
+    // measured optimum is many small workgroups (32 rows x 32 columns, the four waves splitting K) at
+    // high occupancy.  Prefill-sized problems use the tallest tile so that each weight byte is
+    // converted once per 256 rows.
+    int mt, wn, wk;
+    if (M <= 256) { mt = 1; wn = 1; wk = 4; }
+    else { mt = group ? 4 : 8; wn = 4; wk = 1; }
     if (f_mt > 0) mt = f_mt;
     if (f_wn > 0 && f_wk > 0) { wn = f_wn; wk = f_wk; }
     if (!tile_built(mt, wn, wk, group)) { mt = group && mt > 4 ? 4 : mt; wn = 4; wk = 1; }
@@ -398,20 +398,18 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     const int64_t mblocks = (M + 32 * mt - 1) / (32 * mt);
     const int64_t nblocks = (N + 32 * wn - 1) / (32 * wn);
     const int64_t kchunks = (K + kb - 1) / kb;
-    // split K across workgroups until about 2 workgroups per CU exist (256 CUs), keeping >= 2 chunks
-    // (>= 256 k) per slice where possible
+    // split K across workgroups only when the grid would leave most CUs idle, and keep >= 512 k per
+    // slice: below that the extra reduce pass costs more than the parallelism buys
     int64_t split = 1;
     const int64_t base = mblocks * nblocks;
-    const int64_t target = (mt >= 4) ? 256 : 512;
-    if (base < target) {
-        split = (target + base - 1) / base;
-        const int64_t max_split = kchunks >= 2 ? kchunks / 2 : 1;
-        if (split > max_split) split = max_split;
-        if (split < 1) split = 1;
-    }
+    const int64_t max_split = K / 512 > 0 ? K / 512 : 1;
+    if (base < 128) split = (256 + base - 1) / base;
+    else if (base < 512 && K >= 2048) split = 2;
+    if (split > max_split) split = max_split;
     if (f_split > 0) split = f_split;
     if (split > 64) split = 64;
     if (split > kchunks) split = kchunks;
+    if (split < 1) split = 1;
     const int64_t cps = (kchunks + split - 1) / split;      // chunks per slice
     split = (kchunks + cps - 1) / cps;
     pl.split = (int)split;

@@ -1,2 +1,306 @@
-// Placeholder translation unit for the fused elementwise operators around the quantized GEMMs.
+// The operators between the quantized GEMMs of a decoder layer, each as ONE launch so that a decode
+// step is ~10 kernels per layer: residual-add + RMSNorm, per-head q/k RMSNorm + rotary embedding +
+// KV-cache store, SiLU*mul, and single-token (decode) attention over a paged KV cache.
+// All are HBM/L2-bound: 16-byte accesses per lane, f32 math, bf16 storage.
 #include "ql_common.h"
+
+namespace ql {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- y = RMSNorm(x [+ residual]) * w ; residual_out = bf16(x + residual) ------------------------
+// One workgroup per row; the row stays in registers between the two passes (H <= 8192).
+template <int NV>   // 16-byte vectors per thread
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* __restrict__ x,
+                                                          const unsigned short* __restrict__ res,
+                                                          const unsigned short* __restrict__ w,
+                                                          unsigned short* __restrict__ out,
+                                                          unsigned short* __restrict__ res_out, int H, float eps) {
+    __shared__ float sh[4];
+    const size_t row = blockIdx.x;
+    const int nvec = H >> 3;
+    float v[NV][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nvec) {
+            const u16x8 a = *(const u16x8*)(x + row * H + c * 8);
+            if (res) {
+                const u16x8 b = *(const u16x8*)(res + row * H + c * 8);
+                u16x8 r;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[j][k] = bf16_bits_to_f32(a[k]) + bf16_bits_to_f32(b[k]);
+                    r[k] = f32_to_bf16_bits(v[j][k]);
+                }
+                *(u16x8*)(res_out + row * H + c * 8) = r;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[j][k] = bf16_bits_to_f32(a[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += v[j][k] * v[j][k];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = sh[0] + sh[1] + sh[2] + sh[3];
+    const float inv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nvec) {
+            const u16x8 ww = *(const u16x8*)(w + c * 8);
+            u16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                o[k] = f32_to_bf16_bits(round_to_bf16(v[j][k] * inv) * bf16_bits_to_f32(ww[k]));
+            *(u16x8*)(out + row * H + c * 8) = o;
+        }
+    }
+}
+
+// ---- out[t, i] = silu(x[t, i]) * x[t, I + i] -------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_mul_kernel(const unsigned short* __restrict__ x,
+                                                       unsigned short* __restrict__ out, int64_t T, int I) {
+    const int64_t vec_per_row = I >> 3;
+    const int64_t total = T * vec_per_row;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / vec_per_row, c = idx % vec_per_row;
+        const u16x8 a = *(const u16x8*)(x + t * 2 * I + c * 8);
+        const u16x8 b = *(const u16x8*)(x + t * 2 * I + I + c * 8);
+        u16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float g = bf16_bits_to_f32(a[k]);
+            const float s = g / (1.f + __expf(-g));
+            o[k] = f32_to_bf16_bits(s * bf16_bits_to_f32(b[k]));
+        }
+        *(u16x8*)(out + t * I + c * 8) = o;
+    }
+}
+
+// ---- per-head RMSNorm (optional) + rotate-half RoPE on q and k, and K/V scatter into the paged cache
+// One wave per (token, head); head_dim = 128: lane i holds elements i and i + 64, which are exactly
+// the (x1, x2) pair the rotation mixes.
+__global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
+    const unsigned short* __restrict__ qkv, const int64_t* __restrict__ positions,
+    const float* __restrict__ cos_sin, const unsigned short* __restrict__ qw,
+    const unsigned short* __restrict__ kw, float eps, unsigned short* __restrict__ q_out,
+    unsigned short* __restrict__ k_out, unsigned short* __restrict__ v_out,
+    unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
+    const int* __restrict__ slot_mapping, int T, int Hq, int Hkv) {
+    const int lane = threadIdx.x & 63;
+    const int heads = Hq + 2 * Hkv;
+    const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (widx >= (int64_t)T * heads) return;
+    const int t = (int)(widx / heads), h = (int)(widx % heads);
+    const unsigned short* src = qkv + ((size_t)t * heads + h) * 128;
+    float x1 = bf16_bits_to_f32(src[lane]), x2 = bf16_bits_to_f32(src[lane + 64]);
+    const int slot = slot_mapping ? slot_mapping[t] : -1;
+    if (h >= Hq + Hkv) {   // V: copy only
+        const int hv = h - Hq - Hkv;
+        if (v_out) {
+            v_out[((size_t)t * Hkv + hv) * 128 + lane] = src[lane];
+            v_out[((size_t)t * Hkv + hv) * 128 + lane + 64] = src[lane + 64];
+        }
+        if (slot >= 0) {
+            v_cache[((size_t)slot * Hkv + hv) * 128 + lane] = src[lane];
+            v_cache[((size_t)slot * Hkv + hv) * 128 + lane + 64] = src[lane + 64];
+        }
+        return;
+    }
+    const bool is_q = h < Hq;
+    const unsigned short* nw = is_q ? qw : kw;
+    if (nw) {
+        const float ss = wave_sum(x1 * x1 + x2 * x2);
+        const float inv = rsqrtf(ss * (1.f / 128.f) + eps);
+        x1 = round_to_bf16(round_to_bf16(x1 * inv) * bf16_bits_to_f32(nw[lane]));
+        x2 = round_to_bf16(round_to_bf16(x2 * inv) * bf16_bits_to_f32(nw[lane + 64]));
+    }
+    const int64_t pos = positions[t];
+    const float c = cos_sin[pos * 128 + lane], s = cos_sin[pos * 128 + 64 + lane];
+    const unsigned short y1 = f32_to_bf16_bits(x1 * c - x2 * s);
+    const unsigned short y2 = f32_to_bf16_bits(x2 * c + x1 * s);
+    if (is_q) {
+        q_out[((size_t)t * Hq + h) * 128 + lane] = y1;
+        q_out[((size_t)t * Hq + h) * 128 + lane + 64] = y2;
+    } else {
+        const int hk = h - Hq;
+        if (k_out) {
+            k_out[((size_t)t * Hkv + hk) * 128 + lane] = y1;
+            k_out[((size_t)t * Hkv + hk) * 128 + lane + 64] = y2;
+        }
+        if (slot >= 0) {
+            k_cache[((size_t)slot * Hkv + hk) * 128 + lane] = y1;
+            k_cache[((size_t)slot * Hkv + hk) * 128 + lane + 64] = y2;
+        }
+    }
+}
+
+// ---- decode attention over a paged KV cache ------------------------------------------------------
+// grid (batch, kv_head); the G = Hq/Hkv query heads of a kv head share every K/V byte that is read.
+// A wave covers 4 tokens per step: lane = 16 * token_slot + dim_segment, one 16-byte (8 x bf16) load
+// of K and of V per lane and token.  Online softmax per token slot; the 16 slot states of the block
+// are merged through LDS at the end.
+template <int G>
+__global__ __launch_bounds__(256) void paged_attn_decode_kernel(
+    const unsigned short* __restrict__ q, const unsigned short* __restrict__ k_cache,
+    const unsigned short* __restrict__ v_cache, const int* __restrict__ block_tables,
+    const int* __restrict__ context_lens, unsigned short* __restrict__ out, float scale, int Hq, int Hkv,
+    int block_size, int max_blocks) {
+    __shared__ float st_m[16][G], st_l[16][G];
+    __shared__ float st_acc[16][G][128];
+    const int b = blockIdx.x, hk = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane >> 4, seg = lane & 15;
+    const int ctx = context_lens[b];
+    float qv[G][8], acc[G][8], m[G], l[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u16x8 a = *(const u16x8*)(q + ((size_t)b * Hq + hk * G + g) * 128 + seg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { qv[g][j] = bf16_bits_to_f32(a[j]) * scale; acc[g][j] = 0.f; }
+        m[g] = -1e30f;
+        l[g] = 0.f;
+    }
+    const int* bt = block_tables + (size_t)b * max_blocks;
+    for (int t0 = wave * 4 + slot; t0 < ctx; t0 += 16) {
+        const int blk = bt[t0 / block_size];
+        const size_t off = (((size_t)blk * block_size + (t0 % block_size)) * Hkv + hk) * 128 + seg * 8;
+        const u16x8 kk = *(const u16x8*)(k_cache + off);
+        const u16x8 vv = *(const u16x8*)(v_cache + off);
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[j] = bf16_bits_to_f32(kk[j]); vf[j] = bf16_bits_to_f32(vv[j]); }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += qv[g][j] * kf[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            const float mn = fmaxf(m[g], s);
+            const float alpha = __expf(m[g] - mn), pe = __expf(s - mn);
+            l[g] = l[g] * alpha + pe;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] = acc[g][j] * alpha + pe * vf[j];
+            m[g] = mn;
+        }
+    }
+    // note: lanes whose token index ran past ctx simply did fewer iterations (no cross-lane op outside
+    // their own 16-lane token slot is used inside the loop)
+    const int sidx = wave * 4 + slot;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (seg == 0) { st_m[sidx][g] = m[g]; st_l[sidx][g] = l[g]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st_acc[sidx][g][seg * 8 + j] = acc[g][j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < G * 128; o += 256) {
+        const int g = o >> 7, d = o & 127;
+        float mm = -1e30f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) mm = fmaxf(mm, st_m[s][g]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float wgt = __expf(st_m[s][g] - mm);
+            num += wgt * st_acc[s][g][d];
+            den += wgt * st_l[s][g];
+        }
+        out[((size_t)b * Hq + hk * G + g) * 128 + d] = f32_to_bf16_bits(den > 0.f ? num / den : 0.f);
+    }
+}
+
+}  // namespace ql
+
+using namespace ql;
+
+extern "C" {
+
+int ql_add_rmsnorm(const void* x, const void* residual, const void* weight, float eps, void* out, void* residual_out,
+                   int64_t T, int64_t H, void* stream) {
+    if (!weight || T < 0 || H <= 0 || (T > 0 && (!x || !out)) || (residual && !residual_out)) {
+        set_error("ql_add_rmsnorm: bad argument");
+        return QL_EINVAL;
+    }
+    if (H % 8 || H > 8192) { set_error("ql_add_rmsnorm: H=%lld must be a multiple of 8 and <= 8192", (long long)H); return QL_ESHAPE; }
+    if (T == 0) return QL_OK;
+    if (T > 0x7FFFFFFF) { set_error("ql_add_rmsnorm: T too large"); return QL_ESHAPE; }
+    const int nv = (int)((H / 8 + 255) / 256);
+    dim3 grid((unsigned)T), block(256);
+    hipStream_t s = as_stream(stream);
+#define QL_RMS(NV) hipLaunchKernelGGL(add_rmsnorm_kernel<NV>, grid, block, 0, s, (const unsigned short*)x, \
+        (const unsigned short*)residual, (const unsigned short*)weight, (unsigned short*)out, (unsigned short*)residual_out, (int)H, eps)
+    if (nv == 1) QL_RMS(1); else if (nv == 2) QL_RMS(2); else QL_RMS(4);
+#undef QL_RMS
+    QL_CHECK_LAUNCH("ql_add_rmsnorm");
+    return QL_OK;
+}
+
+int ql_silu_mul(const void* x, void* out, int64_t T, int64_t I, void* stream) {
+    if (T < 0 || I <= 0 || (T > 0 && (!x || !out))) { set_error("ql_silu_mul: bad argument"); return QL_EINVAL; }
+    if (I % 8) { set_error("ql_silu_mul: I must be a multiple of 8"); return QL_ESHAPE; }
+    if (T == 0) return QL_OK;
+    int64_t blocks = (T * (I / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const unsigned short*)x,
+                       (unsigned short*)out, T, (int)I);
+    QL_CHECK_LAUNCH("ql_silu_mul");
+    return QL_OK;
+}
+
+int ql_qknorm_rope_store(const void* qkv, const int64_t* positions, const float* cos_sin, const void* q_norm_w,
+                         const void* k_norm_w, float eps, void* q_out, void* k_out, void* v_out, void* k_cache,
+                         void* v_cache, const int* slot_mapping, int64_t T, int Hq, int Hkv, int head_dim, void* stream) {
+    if (T < 0 || Hq <= 0 || Hkv <= 0 || (T > 0 && (!qkv || !positions || !cos_sin || !q_out)) ||
+        (slot_mapping && (!k_cache || !v_cache))) {
+        set_error("ql_qknorm_rope_store: bad argument");
+        return QL_EINVAL;
+    }
+    if (head_dim != 128) { set_error("ql_qknorm_rope_store: head_dim=%d (only 128 is built)", head_dim); return QL_ESHAPE; }
+    if (T == 0) return QL_OK;
+    const int64_t waves = T * (Hq + 2 * Hkv);
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFFF) { set_error("ql_qknorm_rope_store: too many tokens"); return QL_ESHAPE; }
+    hipLaunchKernelGGL(qknorm_rope_store_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       (const unsigned short*)qkv, positions, cos_sin, (const unsigned short*)q_norm_w,
+                       (const unsigned short*)k_norm_w, eps, (unsigned short*)q_out, (unsigned short*)k_out,
+                       (unsigned short*)v_out, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, (int)T,
+                       Hq, Hkv);
+    QL_CHECK_LAUNCH("ql_qknorm_rope_store");
+    return QL_OK;
+}
+
+int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
+                         const int* context_lens, void* out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
+                         int block_size, int max_blocks, void* stream) {
+    if (B < 0 || Hq <= 0 || Hkv <= 0 || block_size <= 0 || max_blocks <= 0 ||
+        (B > 0 && (!q || !k_cache || !v_cache || !block_tables || !context_lens || !out))) {
+        set_error("ql_paged_attn_decode: bad argument");
+        return QL_EINVAL;
+    }
+    if (head_dim != 128 || Hq % Hkv) { set_error("ql_paged_attn_decode: head_dim must be 128 and Hq %% Hkv == 0"); return QL_ESHAPE; }
+    const int G = Hq / Hkv;
+    if (G != 1 && G != 2 && G != 4) { set_error("ql_paged_attn_decode: Hq/Hkv=%d not built (1,2,4)", G); return QL_ESHAPE; }
+    if (B == 0) return QL_OK;
+    if (B > 0x7FFFFFFF || Hkv > 65535) { set_error("ql_paged_attn_decode: batch too large"); return QL_ESHAPE; }
+    dim3 grid((unsigned)B, (unsigned)Hkv), block(256);
+    hipStream_t s = as_stream(stream);
+#define QL_ATT(G_) hipLaunchKernelGGL(paged_attn_decode_kernel<G_>, grid, block, 0, s, (const unsigned short*)q, \
+        (const unsigned short*)k_cache, (const unsigned short*)v_cache, block_tables, context_lens, (unsigned short*)out, \
+        scale, Hq, Hkv, block_size, max_blocks)
+    if (G == 1) QL_ATT(1); else if (G == 2) QL_ATT(2); else QL_ATT(4);
+#undef QL_ATT
+    QL_CHECK_LAUNCH("ql_paged_attn_decode");
+    return QL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+"""Runs the model for one scheduler step on one GPU.  With tensor parallelism every rank is its own
+process (launched by torch.distributed.run) executing the SAME control flow on the same inputs; the
+only cross-rank traffic is the RCCL collectives inside the layers, so no RPC channel is needed."""
+import torch
+import torch.distributed as dist
+
+from nanovllm.config import Config
+from nanovllm.engine.sequence import Sequence
+from nanovllm.models.qwen3 import AttnContext, Qwen3ForCausalLM, set_context
+from nanovllm.utils.loader import init_dummy_weights, load_model
+from nanovllm.utils.quantization import apply_quant_from_config, reserve_workspace
+
+
+class ModelRunner:
+    def __init__(self, config: Config, rank: int = 0):
+        self.config = config
+        hf = config.hf_config
+        self.block_size = config.kvcache_block_size
+        self.enforce_eager = config.enforce_eager
+        self.world_size = config.tensor_parallel_size
+        self.rank = rank
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        default_dtype = torch.get_default_dtype()
+        torch.set_default_dtype(hf.torch_dtype)
+        torch.set_default_device(self.device)
+        try:
+            self.model = Qwen3ForCausalLM(hf)
+            if config.load_format == "dummy":
+                init_dummy_weights(self.model, seed=rank)
+            else:
+                load_model(self.model, config.model)
+            # quantization happens after loading, before warm-up and graph capture (reference:
+            # nanovllm/engine/model_runner.py:36-57)
+            apply_quant_from_config(self.model, config)
+            self._reserve_gemm_workspace()
+            self.allocate_kv_cache()
+            self.graphs = {}
+            if not self.enforce_eager:
+                self.capture_graphs()
+        finally:
+            torch.set_default_device("cpu")
+            torch.set_default_dtype(default_dtype)
+
+    # ------------------------------------------------------------------ setup
+    def _linear_shapes(self):
+        shapes = set()
+        for l in self.model.model.layers:
+            for m in (l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj):
+                w = getattr(m, "qw", None)
+                if w is not None:
+                    shapes.add((w.shape[0], w.shape[1]))
+        return sorted(shapes)
+
+    def _reserve_gemm_workspace(self):
+        shapes = self._linear_shapes()
+        if shapes:
+            reserve_workspace(min(self.config.max_num_seqs, 512), shapes, self.device)
+
+    def allocate_kv_cache(self):
+        cfg, hf = self.config, self.config.hf_config
+        free, total = torch.cuda.mem_get_info()
+        num_kv_heads = hf.num_key_value_heads // self.world_size
+        block_bytes = 2 * hf.num_hidden_layers * self.block_size * num_kv_heads * hf.head_dim * hf.torch_dtype.itemsize
+        # activations of the largest prefill batch stay well under 10 GiB for every supported size
+        budget = int(free - (1.0 - cfg.gpu_memory_utilization) * total) - (10 << 30)
+        max_needed = cfg.max_num_seqs * ((cfg.max_model_len + self.block_size - 1) // self.block_size)
+        cfg.num_kvcache_blocks = max(1, min(budget // block_bytes, max_needed))
+        assert cfg.num_kvcache_blocks > 0
+        self.kv_cache = torch.empty(2, hf.num_hidden_layers, cfg.num_kvcache_blocks, self.block_size, num_kv_heads,
+                                    hf.head_dim)
+        for i, layer in enumerate(self.model.model.layers):
+            layer.self_attn.k_cache = self.kv_cache[0, i]
+            layer.self_attn.v_cache = self.kv_cache[1, i]
+
+    # ------------------------------------------------------------------ per-step input preparation
+    def _dev(self, data, dtype):
+        return torch.tensor(data, dtype=dtype, pin_memory=True).to(self.device, non_blocking=True)
+
+    def prepare_prefill(self, seqs):
+        input_ids, positions, slot_mapping, cu = [], [], [], [0]
+        for seq in seqs:
+            n = len(seq)
+            input_ids.extend(seq.token_ids)
+            positions.extend(range(n))
+            cu.append(cu[-1] + n)
+            for i, blk in enumerate(seq.block_table):
+                start = blk * self.block_size
+                cnt = self.block_size if i != seq.num_blocks - 1 else seq.last_block_num_tokens
+                slot_mapping.extend(range(start, start + cnt))
+        if not slot_mapping:           # warm-up sequences own no blocks
+            slot = None
+        else:
+            slot = self._dev(slot_mapping, torch.int32)
+        set_context(AttnContext(is_prefill=True, cu_seqlens=cu, slot_mapping=slot))
+        return self._dev(input_ids, torch.int64), self._dev(positions, torch.int64), cu
+
+    def prepare_decode(self, seqs):
+        input_ids = [s.last_token for s in seqs]
+        positions = [len(s) - 1 for s in seqs]
+        context_lens = [len(s) for s in seqs]
+        slot_mapping = [s.block_table[-1] * self.block_size + s.last_block_num_tokens - 1 for s in seqs]
+        width = max(len(s.block_table) for s in seqs)
+        tables = [s.block_table + [0] * (width - len(s.block_table)) for s in seqs]
+        return (self._dev(input_ids, torch.int64), self._dev(positions, torch.int64),
+                self._dev(slot_mapping, torch.int32), self._dev(context_lens, torch.int32),
+                self._dev(tables, torch.int32))
+
+    # ------------------------------------------------------------------ execution
+    @torch.inference_mode()
+    def run(self, seqs, is_prefill: bool):
+        if is_prefill:
+            ids, pos, cu = self.prepare_prefill(seqs)
+            h = self.model(ids, pos)
+            last = torch.tensor(cu[1:], device=self.device) - 1
+            logits = self.model.compute_logits(h[last].contiguous())
+        else:
+            ids, pos, slots, ctx_lens, tables = self.prepare_decode(seqs)
+            bs = ids.numel()
+            if self.enforce_eager or bs > self.max_graph_bs:
+                set_context(AttnContext(False, None, slots, ctx_lens, tables))
+                logits = self.model.compute_logits(self.model(ids, pos))
+            else:
+                gbs = next(x for x in self.graph_bs if x >= bs)
+                gv = self.graph_vars
+                gv["input_ids"][:bs] = ids
+                gv["positions"][:bs] = pos
+                gv["slot_mapping"].fill_(-1)
+                gv["slot_mapping"][:bs] = slots
+                gv["context_lens"].zero_()
+                gv["context_lens"][:bs] = ctx_lens
+                gv["block_tables"][:bs, :tables.shape[1]] = tables
+                self.graphs[gbs].replay()
+                logits = gv["logits"][:bs]
+        token_ids = logits.argmax(dim=-1).tolist()     # greedy sampler (layers/sampler.py:10-12)
+        return token_ids
+
+    @torch.inference_mode()
+    def capture_graphs(self):
+        cfg, hf = self.config, self.config.hf_config
+        max_bs = min(cfg.max_num_seqs, 512)
+        self.max_graph_bs = max_bs
+        max_blocks = (cfg.max_model_len + self.block_size - 1) // self.block_size
+        gv = dict(
+            input_ids=torch.zeros(max_bs, dtype=torch.int64),
+            positions=torch.zeros(max_bs, dtype=torch.int64),
+            slot_mapping=torch.full((max_bs,), -1, dtype=torch.int32),
+            context_lens=torch.zeros(max_bs, dtype=torch.int32),
+            block_tables=torch.zeros(max_bs, max_blocks, dtype=torch.int32),
+            logits=torch.zeros(max_bs, hf.vocab_size),
+        )
+        self.graph_bs = [1, 2, 4, 8] + list(range(16, max_bs + 1, 16))
+        pool = None
+        for bs in reversed(self.graph_bs):
+            set_context(AttnContext(False, None, gv["slot_mapping"][:bs], gv["context_lens"][:bs], gv["block_tables"][:bs]))
+            gv["logits"][:bs] = self.model.compute_logits(self.model(gv["input_ids"][:bs], gv["positions"][:bs]))  # warm-up
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool):
+                gv["logits"][:bs] = self.model.compute_logits(self.model(gv["input_ids"][:bs], gv["positions"][:bs]))
+            if pool is None:
+                pool = g.pool()
+            self.graphs[bs] = g
+        torch.cuda.synchronize()
+        self.graph_vars = gv

@@ -1,0 +1,200 @@
+"""Qwen3 decoder (the only model family of the reference, nanovllm/models/qwen3.py) as the host of
+the four quantized-linear call sites per layer.  Everything between the GEMMs runs as one fused HIP
+launch per operator (nanovllm/ops.py); attention is torch SDPA for prefill and a paged single-query
+kernel for decode."""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from nanovllm import ops
+from nanovllm.layers.linear import (MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear, _tp_world,
+                                    tp_all_reduce)
+
+
+@dataclass
+class AttnContext:
+    """Per-step attention metadata (the reference keeps it in a module global, utils/context.py)."""
+    is_prefill: bool = False
+    cu_seqlens: Optional[list] = None          # python list, prefill only
+    slot_mapping: Optional[torch.Tensor] = None
+    context_lens: Optional[torch.Tensor] = None
+    block_tables: Optional[torch.Tensor] = None
+
+
+_CTX = AttnContext()
+
+
+def set_context(ctx: AttnContext):
+    global _CTX
+    _CTX = ctx
+
+
+def get_context() -> AttnContext:
+    return _CTX
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size: int, eps: float = 1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(hidden_size), requires_grad=False)
+
+    def forward(self, x, residual=None):
+        out, res = ops.add_rmsnorm(x, residual, self.weight, self.eps)
+        return out if residual is None else (out, res)
+
+
+class VocabParallelEmbedding(nn.Module):
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.tp_rank, self.tp_size = _tp_world()
+        assert num_embeddings % self.tp_size == 0
+        self.per_part = num_embeddings // self.tp_size
+        self.start = self.per_part * self.tp_rank
+        self.weight = nn.Parameter(torch.empty(self.per_part, embedding_dim), requires_grad=False)
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param, loaded_weight):
+        param.data.copy_(loaded_weight.narrow(0, self.start, self.per_part))
+
+    def forward(self, x):
+        if self.tp_size > 1:
+            mask = (x >= self.start) & (x < self.start + self.per_part)
+            x = mask * (x - self.start)
+        y = F.embedding(x, self.weight)
+        if self.tp_size > 1:
+            y = mask.unsqueeze(1) * y
+            y = tp_all_reduce(y)
+        return y
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    """bf16 (unquantized, as in the reference) vocab-parallel output projection; with TP the shards'
+    logits are all-gathered so every rank can take the same argmax."""
+
+    def forward(self, x):
+        logits = F.linear(x, self.weight)
+        if self.tp_size > 1:
+            parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
+            dist.all_gather(parts, logits)
+            logits = torch.cat(parts, -1)
+        return logits
+
+
+class Qwen3Attention(nn.Module):
+    def __init__(self, cfg, cos_sin):
+        super().__init__()
+        _, tp = _tp_world()
+        self.num_heads = cfg.num_attention_heads // tp
+        self.num_kv_heads = cfg.num_key_value_heads // tp
+        self.head_dim = cfg.head_dim
+        self.scaling = self.head_dim ** -0.5
+        self.eps = cfg.rms_norm_eps
+        self.qkv_bias = cfg.attention_bias
+        self.qkv_proj = QKVParallelLinear(cfg.hidden_size, self.head_dim, cfg.num_attention_heads,
+                                          cfg.num_key_value_heads, bias=self.qkv_bias)
+        self.o_proj = RowParallelLinear(cfg.num_attention_heads * self.head_dim, cfg.hidden_size, bias=False)
+        if not self.qkv_bias:
+            self.q_norm = RMSNorm(self.head_dim, eps=self.eps)
+            self.k_norm = RMSNorm(self.head_dim, eps=self.eps)
+        self.cos_sin = cos_sin
+        self.k_cache = self.v_cache = torch.tensor([])
+
+    def forward(self, positions, hidden_states):
+        ctx = get_context()
+        qkv = self.qkv_proj(hidden_states)
+        qw = self.q_norm.weight if not self.qkv_bias else None
+        kw = self.k_norm.weight if not self.qkv_bias else None
+        q, k, v = ops.qknorm_rope_store(qkv, positions, self.cos_sin, qw, kw, self.eps, self.num_heads,
+                                        self.num_kv_heads, self.head_dim, self.k_cache, self.v_cache,
+                                        ctx.slot_mapping, want_kv=ctx.is_prefill)
+        if ctx.is_prefill:
+            o = torch.empty_like(q)
+            cu = ctx.cu_seqlens
+            for i in range(len(cu) - 1):
+                a, b = cu[i], cu[i + 1]
+                o[a:b] = F.scaled_dot_product_attention(
+                    q[a:b].transpose(0, 1).unsqueeze(0), k[a:b].transpose(0, 1).unsqueeze(0),
+                    v[a:b].transpose(0, 1).unsqueeze(0), is_causal=True, scale=self.scaling,
+                    enable_gqa=self.num_heads != self.num_kv_heads)[0].transpose(0, 1)
+        else:
+            o = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scaling)
+        return self.o_proj(o.view(o.shape[0], -1))
+
+
+class Qwen3MLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.hidden_act == "silu"
+        self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=False)
+        self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(ops.silu_mul(self.gate_up_proj(x)))
+
+
+class Qwen3DecoderLayer(nn.Module):
+    def __init__(self, cfg, cos_sin):
+        super().__init__()
+        self.self_attn = Qwen3Attention(cfg, cos_sin)
+        self.mlp = Qwen3MLP(cfg)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states), residual
+
+
+def build_cos_sin(head_dim, max_position, base, device):
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float, device=device) / head_dim))
+    t = torch.arange(max_position, dtype=torch.float, device=device)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).contiguous()   # [max_pos, head_dim] f32
+
+
+class Qwen3Model(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        dev = torch.empty(0).device
+        self.cos_sin = build_cos_sin(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, dev)
+        self.embed_tokens = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([Qwen3DecoderLayer(cfg, self.cos_sin) for _ in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+
+    def forward(self, input_ids, positions):
+        hidden_states = self.embed_tokens(input_ids)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class Qwen3ForCausalLM(nn.Module):
+    packed_modules_mapping = {
+        "q_proj": ("qkv_proj", "q"), "k_proj": ("qkv_proj", "k"), "v_proj": ("qkv_proj", "v"),
+        "gate_proj": ("gate_up_proj", 0), "up_proj": ("gate_up_proj", 1),
+    }
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.model = Qwen3Model(cfg)
+        self.lm_head = ParallelLMHead(cfg.vocab_size, cfg.hidden_size)
+        if cfg.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    def forward(self, input_ids, positions):
+        return self.model(input_ids, positions)
+
+    def compute_logits(self, hidden_states):
+        return self.lm_head(hidden_states)

@@ -1,0 +1,66 @@
+"""Thin wrappers over the non-GEMM entry points of libqlinear (norm, activation, rope+KV store,
+decode attention).  GPU only; every call is one kernel launch on the current stream."""
+import torch
+
+from nanovllm import _qlinear as Q
+
+BF16 = torch.bfloat16
+
+
+def add_rmsnorm(x, residual, weight, eps):
+    """Returns (normed, new_residual); new_residual is x when residual is None."""
+    Q.require_cuda(x, BF16, "x")
+    H = x.shape[-1]
+    T = x.numel() // H
+    out = torch.empty_like(x)
+    if residual is None:
+        Q.check(Q.load().ql_add_rmsnorm(x.data_ptr(), None, weight.data_ptr(), eps, out.data_ptr(), None, T, H,
+                                        Q.stream_ptr(x.device)))
+        return out, x
+    Q.require_cuda(residual, BF16, "residual")
+    res_out = torch.empty_like(x)
+    Q.check(Q.load().ql_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), eps, out.data_ptr(),
+                                    res_out.data_ptr(), T, H, Q.stream_ptr(x.device)))
+    return out, res_out
+
+
+def silu_mul(x):
+    Q.require_cuda(x, BF16, "x")
+    I = x.shape[-1] // 2
+    T = x.numel() // (2 * I)
+    out = torch.empty(list(x.shape[:-1]) + [I], dtype=BF16, device=x.device)
+    Q.check(Q.load().ql_silu_mul(x.data_ptr(), out.data_ptr(), T, I, Q.stream_ptr(x.device)))
+    return out
+
+
+def qknorm_rope_store(qkv, positions, cos_sin, q_norm_w, k_norm_w, eps, num_heads, num_kv_heads, head_dim,
+                      k_cache=None, v_cache=None, slot_mapping=None, want_kv=True):
+    """qkv [T, (Hq+2Hkv)*D] -> q [T,Hq,D] (and contiguous k, v [T,Hkv,D] when want_kv), writing k/v into
+    the paged cache rows named by slot_mapping."""
+    Q.require_cuda(qkv, BF16, "qkv")
+    T = qkv.shape[0]
+    q = torch.empty((T, num_heads, head_dim), dtype=BF16, device=qkv.device)
+    k = torch.empty((T, num_kv_heads, head_dim), dtype=BF16, device=qkv.device) if want_kv else None
+    v = torch.empty((T, num_kv_heads, head_dim), dtype=BF16, device=qkv.device) if want_kv else None
+    use_cache = slot_mapping is not None and k_cache is not None and k_cache.numel() > 0
+    Q.check(Q.load().ql_qknorm_rope_store(
+        qkv.data_ptr(), positions.data_ptr(), cos_sin.data_ptr(),
+        q_norm_w.data_ptr() if q_norm_w is not None else None,
+        k_norm_w.data_ptr() if k_norm_w is not None else None, eps, q.data_ptr(),
+        k.data_ptr() if want_kv else None, v.data_ptr() if want_kv else None,
+        k_cache.data_ptr() if use_cache else None, v_cache.data_ptr() if use_cache else None,
+        slot_mapping.data_ptr() if use_cache else None, T, num_heads, num_kv_heads, head_dim,
+        Q.stream_ptr(qkv.device)))
+    return q, k, v
+
+
+def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale):
+    """q [B,Hq,D]; caches [num_blocks, block_size, Hkv, D] -> out [B,Hq,D]."""
+    Q.require_cuda(q, BF16, "q")
+    B, Hq, D = q.shape
+    _, block_size, Hkv, _ = k_cache.shape
+    out = torch.empty_like(q)
+    Q.check(Q.load().ql_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                          context_lens.data_ptr(), out.data_ptr(), scale, B, Hq, Hkv, D, block_size,
+                                          block_tables.shape[1], Q.stream_ptr(q.device)))
+    return out

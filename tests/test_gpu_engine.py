@@ -1,0 +1,244 @@
+"""GPU tests of the plumbing around the quantized linears: the fused norm / rope / activation /
+decode-attention launches against plain PyTorch fp32 references of the same operators, and the
+engine (scheduler + runner + hipGraph decode) end to end on a tiny random Qwen3."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(architectures=["Qwen3ForCausalLM"], hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+            num_key_value_heads=2, head_dim=128, intermediate_size=512, vocab_size=1024, rms_norm_eps=1e-6,
+            rope_theta=1000000.0, max_position_embeddings=2048, tie_word_embeddings=True, attention_bias=False,
+            hidden_act="silu", torch_dtype="bfloat16")
+
+
+@pytest.fixture(scope="module")
+def tiny_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("tiny_qwen3")
+    with open(d / "config.json", "w") as f:
+        json.dump(TINY, f)
+    return str(d)
+
+
+def _close(a, b, rtol=2e-2, atol=2e-2):
+    a, b = a.float(), b.float()
+    assert torch.isfinite(a).all()
+    err = (a - b).abs()
+    assert (err <= atol + rtol * b.abs()).all(), f"max err {err.max().item()} at scale {b.abs().max().item()}"
+
+
+# ----------------------------------------------------------------------------- operators
+def test_add_rmsnorm_matches_torch():
+    from nanovllm import ops
+    torch.manual_seed(0)
+    for T, H in [(1, 128), (7, 1024), (300, 4096), (3, 8192)]:
+        x = torch.randn(T, H, device="cuda", dtype=torch.bfloat16)
+        r = torch.randn(T, H, device="cuda", dtype=torch.bfloat16)
+        w = (1 + 0.1 * torch.randn(H, device="cuda")).to(torch.bfloat16)
+        out, res = ops.add_rmsnorm(x, r, w, 1e-6)
+        s = x.float() + r.float()
+        ref_res = s.to(torch.bfloat16)
+        ref = (s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16) * w
+        assert torch.equal(res, ref_res)
+        _close(out, ref, rtol=2 ** -6, atol=1e-6)
+        out2, res2 = ops.add_rmsnorm(x, None, w, 1e-6)
+        xf = x.float()
+        ref2 = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16) * w
+        _close(out2, ref2, rtol=2 ** -6, atol=1e-6)
+        assert res2 is x
+
+
+def test_silu_mul_matches_torch():
+    from nanovllm import ops
+    torch.manual_seed(1)
+    for T, I in [(1, 64), (5, 3072), (257, 9728)]:
+        x = torch.randn(T, 2 * I, device="cuda", dtype=torch.bfloat16) * 3
+        ref = F.silu(x[:, :I].float()) * x[:, I:].float()
+        _close(ops.silu_mul(x), ref, rtol=2 ** -7, atol=1e-5)
+
+
+def _rope_ref(x, pos, cos_sin):
+    cs = cos_sin[pos]                                   # [T, 128]
+    cos, sin = cs[:, None, :64], cs[:, None, 64:]
+    x1, x2 = x.float()[..., :64], x.float()[..., 64:]
+    return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), -1).to(x.dtype)
+
+
+def test_qknorm_rope_store_matches_torch():
+    from nanovllm import ops
+    from nanovllm.models.qwen3 import build_cos_sin
+    torch.manual_seed(2)
+    T, Hq, Hkv, D = 37, 4, 2, 128
+    cos_sin = build_cos_sin(D, 512, 1e6, "cuda")
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * D, device="cuda", dtype=torch.bfloat16)
+    pos = torch.randint(0, 512, (T,), device="cuda")
+    qw = (1 + 0.1 * torch.randn(D, device="cuda")).to(torch.bfloat16)
+    kw = (1 + 0.1 * torch.randn(D, device="cuda")).to(torch.bfloat16)
+    kc = torch.zeros(4, 256, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    slots = torch.randperm(1024, device="cuda")[:T].to(torch.int32)
+    slots[3] = -1
+    q, k, v = ops.qknorm_rope_store(qkv, pos, cos_sin, qw, kw, 1e-6, Hq, Hkv, D, kc, vc, slots)
+
+    def norm(x, w):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16) * w
+    q0, k0, v0 = qkv.split([Hq * D, Hkv * D, Hkv * D], -1)
+    q_ref = _rope_ref(norm(q0.view(T, Hq, D), qw), pos, cos_sin)
+    k_ref = _rope_ref(norm(k0.view(T, Hkv, D), kw), pos, cos_sin)
+    _close(q, q_ref, rtol=2 ** -6, atol=2e-3)
+    _close(k, k_ref, rtol=2 ** -6, atol=2e-3)
+    assert torch.equal(v, v0.view(T, Hkv, D))
+    live = slots >= 0
+    assert torch.equal(kc.view(-1, Hkv, D)[slots[live].long()], k[live])
+    assert torch.equal(vc.view(-1, Hkv, D)[slots[live].long()], v[live])
+    assert kc.view(-1, Hkv, D).abs().sum(dim=(1, 2)).ne(0).sum().item() == int(live.sum())
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_paged_attn_decode_matches_torch(G):
+    from nanovllm import ops
+    torch.manual_seed(3)
+    B, Hkv, D, bs = 9, 2, 128, 256
+    Hq = Hkv * G
+    lens = [1, 5, 16, 17, 255, 256, 257, 700, 0]
+    nblk = sum((l + bs - 1) // bs for l in lens) + 1
+    kc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    tables = torch.zeros(B, 4, dtype=torch.int32, device="cuda")
+    nxt = 1
+    for b, l in enumerate(lens):
+        for j in range((l + bs - 1) // bs):
+            tables[b, j] = nxt
+            nxt += 1
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.bfloat16)
+    ctx = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5)
+    for b, l in enumerate(lens):
+        if l == 0:
+            assert out[b].abs().max().item() == 0
+            continue
+        idx = torch.cat([tables[b, j].long() * bs + torch.arange(bs, device="cuda") for j in range((l + bs - 1) // bs)])[:l]
+        k = kc.view(-1, Hkv, D)[idx].float().repeat_interleave(G, dim=1)   # [l, Hq, D]
+        v = vc.view(-1, Hkv, D)[idx].float().repeat_interleave(G, dim=1)
+        s = torch.einsum("hd,lhd->hl", q[b].float(), k) * D ** -0.5
+        ref = torch.einsum("hl,lhd->hd", s.softmax(-1), v)
+        _close(out[b], ref, rtol=2 ** -6, atol=2e-2)
+
+
+# ----------------------------------------------------------------------------- engine
+def _prompts(n=4):
+    g = torch.Generator().manual_seed(0)
+    return [torch.randint(0, 1000, (int(l),), generator=g).tolist() for l in torch.randint(3, 40, (n,), generator=g)]
+
+
+def _ref_forward(model, ids):
+    """Plain PyTorch forward of the same (unquantized) weights for one sequence: fp32 math."""
+    m = model.model
+    T = len(ids)
+    pos = torch.arange(T, device="cuda")
+    x = F.embedding(torch.tensor(ids, device="cuda"), m.embed_tokens.weight).float()
+
+    def rms(v, w, eps=1e-6):
+        return v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + eps) * w.float()
+    for l in m.layers:
+        a = l.self_attn
+        h = rms(x, l.input_layernorm.weight)
+        qkv = h @ a.qkv_proj.weight.float().T
+        q, k, v = qkv.split([a.num_heads * 128, a.num_kv_heads * 128, a.num_kv_heads * 128], -1)
+        q = rms(q.view(T, -1, 128), a.q_norm.weight)
+        k = rms(k.view(T, -1, 128), a.k_norm.weight)
+        q, k = _rope_ref(q, pos, m.cos_sin).float(), _rope_ref(k, pos, m.cos_sin).float()
+        v = v.view(T, -1, 128)
+        o = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None],
+                                           is_causal=True, enable_gqa=True)[0].transpose(0, 1).reshape(T, -1)
+        x = x + o @ a.o_proj.weight.float().T
+        h = rms(x, l.post_attention_layernorm.weight)
+        gu = h @ l.mlp.gate_up_proj.weight.float().T
+        I = gu.shape[-1] // 2
+        x = x + (F.silu(gu[:, :I]) * gu[:, I:]) @ l.mlp.down_proj.weight.float().T
+    return rms(x, m.norm.weight) @ model.lm_head.weight.float().T
+
+
+def test_engine_bf16_eager_matches_torch_reference_and_graph(tiny_dir):
+    from nanovllm import LLM, SamplingParams
+    sp = SamplingParams(temperature=0.6, max_tokens=12, ignore_eos=True)
+    prompts = _prompts()
+    eager = LLM(tiny_dir, load_format="dummy", enforce_eager=True, max_model_len=512, max_num_seqs=16)
+    out_e = eager.generate(prompts, sp)
+    assert [len(o["token_ids"]) for o in out_e] == [12] * 4
+    # greedy continuation by the fp32 PyTorch forward of the same weights: same first tokens
+    model = eager.model_runner.model
+    agree = 0
+    for p, o in zip(prompts, out_e):
+        logits = _ref_forward(model, p)[-1]
+        top2 = logits.topk(2).values
+        if o["token_ids"][0] == int(logits.argmax()):
+            agree += 1
+        else:   # allow a flip only when the fp32 reference itself is nearly tied
+            assert (top2[0] - top2[1]).item() < 0.05 * logits.abs().max().item()
+    assert agree >= 3
+    # decode through captured hipGraphs gives exactly the eager tokens (same kernels, same order)
+    graph = LLM(tiny_dir, load_format="dummy", enforce_eager=False, max_model_len=512, max_num_seqs=16)
+    out_g = graph.generate(prompts, sp)
+    assert [o["token_ids"] for o in out_g] == [o["token_ids"] for o in out_e]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(quant_type="per_row_weight_only", linear_dtype=torch.int8),
+    dict(quant_type="per_row", linear_dtype=torch.int8),
+    dict(quant_type="per_row", linear_dtype=torch.float8_e4m3fn),
+    dict(quant_type="per_group", linear_dtype=torch.int8, group_size=128),
+    dict(quant_type="per_tensor", linear_dtype=torch.int8),
+    dict(linear_dtype=torch.int8),   # no quant_type: non-bf16 linear dtype means per-row (model_runner.py:55-57)
+])
+def test_engine_quantized_variants(tiny_dir, kw):
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.models.qwen3 import AttnContext, set_context
+    from nanovllm.utils import quantization as NQ
+    llm = LLM(tiny_dir, load_format="dummy", enforce_eager=False, max_model_len=512, max_num_seqs=16, **kw)
+    layer = llm.model_runner.model.model.layers[0]
+    want = {"per_group": NQ.QGroupLinear, "per_tensor": NQ.QTensorLinear}.get(kw.get("quant_type"), NQ.QLinear)
+    for m in (layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj, layer.mlp.down_proj):
+        assert isinstance(m, want)
+    out = llm.generate(_prompts(), SamplingParams(max_tokens=8, ignore_eos=True))
+    assert all(len(o["token_ids"]) == 8 for o in out)
+    # hidden states stay close to the unquantized model with the same (seeded) weights
+    ref = LLM(tiny_dir, load_format="dummy", enforce_eager=True, max_model_len=512, max_num_seqs=16)
+    ids = torch.tensor(_prompts(1)[0], device="cuda")
+    pos = torch.arange(ids.numel(), device="cuda")
+    with torch.inference_mode():
+        hs = []
+        for e in (ref, llm):
+            set_context(AttnContext(is_prefill=True, cu_seqlens=[0, ids.numel()], slot_mapping=None))
+            hs.append(e.model_runner.model(ids, pos).float())
+    rel = (hs[0] - hs[1]).abs().max() / hs[0].abs().max()
+    assert rel < 0.1, float(rel)
+
+
+def test_weight_fake_quant_dispatch(tiny_dir):
+    """weight_quant_fn takes precedence and keeps bf16 linears (model_runner.py:37-39)."""
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.layers.linear import LinearBase
+    from nanovllm.utils import quantization as NQ
+    llm = LLM(tiny_dir, load_format="dummy", enforce_eager=True, max_model_len=512, max_num_seqs=16,
+              weight_quant_fn=lambda w: NQ.fake_per_row_quant(w, torch.int8), quant_type="per_row",
+              linear_dtype=torch.int8)
+    assert isinstance(llm.model_runner.model.model.layers[0].mlp.down_proj, LinearBase)
+    out = llm.generate(_prompts(2), SamplingParams(max_tokens=4, ignore_eos=True))
+    assert all(len(o["token_ids"]) == 4 for o in out)
+
+
+def test_scheduler_continuous_batching_and_finish(tiny_dir):
+    """More sequences than max_num_seqs, different lengths: all finish with exactly max_tokens."""
+    from nanovllm import LLM, SamplingParams
+    llm = LLM(tiny_dir, load_format="dummy", enforce_eager=False, max_model_len=512, max_num_seqs=4,
+              quant_type="per_row_weight_only", linear_dtype=torch.int8)
+    prompts = _prompts(9)
+    sps = [SamplingParams(max_tokens=3 + i, ignore_eos=True) for i in range(9)]
+    out = llm.generate(prompts, sps)
+    assert [len(o["token_ids"]) for o in out] == [3 + i for i in range(9)]
