@@ -1,0 +1,225 @@
+"""Headline benchmark: tokens/s of Qwen3-0.6B with INT8 weight-only (W8A16, per-output-channel
+scales) quantized linears on the reference bench.py's synthetic 256-sequence workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over one batch of synthetic input = one generate() of the
+256 sequences (random token prompts of 100-1024 tokens, 100-1024 new tokens each, seed 0: exactly
+the reference bench.py's workload; sum(max_tokens) = 133,966 output tokens per step).  Weights are
+random-initialised (no checkpoint on the box); data: synthetic.  With N > 1 the model runs tensor-
+parallel over N GPUs (one process per GPU, RCCL all-reduce in the row-parallel linears): the total
+work is fixed, so scaling is "strong".
+
+Rank 0 prints one JSON line with the metric, a `roofline` object for the dominant kernel (the decode
+W8A16 GEMM, HBM-bound: algorithmic bytes / launch duration measured with HIP events) and a
+`cpu_baseline` object (the reference's CPU arithmetic for the same linears, timed on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from random import randint, seed
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nano-vllm-hw3_amd"))
+sys.path.insert(0, ROOT)
+
+QWEN3_06B = dict(architectures=["Qwen3ForCausalLM"], hidden_size=1024, num_hidden_layers=28, num_attention_heads=16,
+                 num_key_value_heads=8, head_dim=128, intermediate_size=3072, vocab_size=151936, rms_norm_eps=1e-6,
+                 rope_theta=1000000.0, max_position_embeddings=40960, tie_word_embeddings=True, attention_bias=False,
+                 hidden_act="silu", torch_dtype="bfloat16", eos_token_id=151645)
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak
+
+
+def workload():
+    """The reference bench.py's inputs (bench.py:9-18 there)."""
+    seed(0)
+    prompts = [[randint(0, 10000) for _ in range(randint(100, 1024))] for _ in range(256)]
+    max_tokens = [randint(100, 1024) for _ in range(256)]
+    return prompts, max_tokens
+
+
+def gemm_bytes(M, N, K):
+    """Algorithmic bytes of one W8A16 linear call: 1-byte weights + f32 row scales + bf16 x in + bf16 y out."""
+    return N * K + 4 * N + 2 * M * K + 2 * M * N
+
+
+def measure_decode_gemm(llm, step_batches):
+    """Average duration of the decode GEMM launches with HIP events on the launch stream, over the
+    (batch bucket, layer shape) mix the timed region actually ran; returns the roofline object."""
+    from nanovllm.utils.quantization import QLinear
+    runner = llm.model_runner
+    buckets = {}
+    for bs in step_batches:
+        g = next(x for x in runner.graph_bs if x >= bs) if not runner.enforce_eager else bs
+        buckets[g] = buckets.get(g, 0) + 1
+    layers = runner.model.model.layers
+    mods = [[l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj] for l in layers]
+    if not isinstance(mods[0][0], QLinear):
+        return None
+    stream = torch.cuda.current_stream()
+    tot_t = tot_b = tot_n = 0.0
+    busy = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    with torch.inference_mode():
+        for M, cnt in sorted(buckets.items()):
+            xs = [torch.randn(M, m.qw.shape[1], device="cuda", dtype=torch.bfloat16) for m in mods[0]]
+            for m4 in mods[:2]:          # untimed: touch the code path for this M
+                for x, m in zip(xs, m4):
+                    m(x)
+            torch.cuda.synchronize()
+            # keep the GPU busy while the host enqueues the bracketed launches, so that each event pair
+            # times the kernel(s) of one linear call and not the host's launch latency; the busy GEMMs
+            # also flush L2 / Infinity Cache, so the weights stream from HBM as they do in the real step
+            for _ in range(8):
+                torch.mm(busy, busy)
+            evs = []
+            for m4 in mods:
+                for x, m in zip(xs, m4):
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record(stream)
+                    m(x)
+                    e.record(stream)
+                    evs.append((s, e, gemm_bytes(M, m.qw.shape[0], m.qw.shape[1])))
+            torch.cuda.synchronize()
+            for s, e, b in evs:
+                tot_t += s.elapsed_time(e) * 1e-3 * cnt
+                tot_b += b * cnt
+                tot_n += cnt
+    if tot_n == 0:
+        return None
+    avg_us = tot_t / tot_n * 1e6
+    achieved = tot_b / tot_t / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "ql::qgemm_kernel (decode W8A16 GEMM, all four layer shapes, M = graph bucket)",
+            "avg_launch_us": round(avg_us, 2), "avg_algorithmic_bytes": int(tot_b / tot_n),
+            "launches_weighted": int(tot_n)}
+
+
+def cpu_baseline():
+    """The reference's CPU-runnable forward arithmetic for the same linears (x.float() @ (qw.float()*sw).T,
+    torch.matmul) on this box's host cores: all 112 quantized linears of one Qwen3-0.6B decode step at
+    M = 128 rows.  A reported baseline only."""
+    from oracle.qlinear_oracle import cpu_reference_linear_torch
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    M = 128
+    shapes = [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072)]
+    g = torch.Generator().manual_seed(0)
+    ws = [(torch.randint(-127, 128, (n, k), dtype=torch.int8, generator=g), torch.rand(n, generator=g) * 1e-3 + 1e-4)
+          for n, k in shapes]
+    xs = [torch.randn(M, k, generator=g).to(torch.bfloat16) for _, k in shapes]
+    for (q, s), x in zip(ws, xs):
+        cpu_reference_linear_torch(x, q, s)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 10.0:
+        for _ in range(28):
+            for (q, s), x in zip(ws, xs):
+                cpu_reference_linear_torch(x, q, s)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(M / dt, 1), "unit": "tokens/s (quantized linears of one decode step only)", "cores": threads,
+            "kind": "port",
+            "sample": f"{reps} x [28 layers x 4 Qwen3-0.6B linears at M=128]: x.float() @ (qw.float()*sw).T via torch.matmul, "
+                      f"{threads} threads, ~10 s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--quant", default="per_row_weight_only",
+                    choices=["per_row_weight_only", "per_row", "per_group", "per_tensor", "bf16"])
+    ap.add_argument("--dtype", default="int8", choices=["int8", "fp8"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from nanovllm import LLM, SamplingParams
+    model_dir = tempfile.mkdtemp(prefix=f"qwen3_06b_r{rank}_")
+    with open(os.path.join(model_dir, "config.json"), "w") as f:
+        json.dump(QWEN3_06B, f)
+    kw = dict(enforce_eager=False, max_model_len=4096, load_format="dummy", tensor_parallel_size=world)
+    if args.quant != "bf16":
+        kw.update(quant_type=args.quant, linear_dtype=torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn,
+                  group_size=128)
+    llm = LLM(model_dir, **kw)
+
+    prompts, max_tokens = workload()
+    sps = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m) for m in max_tokens]
+    total_tokens = sum(max_tokens)
+
+    # record the decode batch size of every step of one pass (for the roofline mix)
+    step_batches = []
+    orig_step = llm.step
+
+    def logged_step():
+        out, n = orig_step()
+        if n < 0:
+            step_batches.append(-n)
+        return out, n
+    llm.step = logged_step
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        # same shapes as the timed pass but one tenth of the decode length: warms graphs and allocator
+        llm.generate(prompts, [SamplingParams(ignore_eos=True, max_tokens=max(8, m // 10)) for m in max_tokens])
+    step_batches.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        llm.generate(prompts, sps)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = None
+    if rank == 0 and not args.no_roofline and args.quant != "bf16":
+        roof = measure_decode_gemm(llm, step_batches[: len(step_batches) // max(args.steps, 1)])
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        dtype = "bf16" if args.quant in ("bf16", "per_row_weight_only", "per_group", "per_tensor") else args.dtype
+        line = {
+            "metric": "tokens/s Qwen3-0.6B INT8, 256 seqs (bench.py)", "value": round(args.steps * total_tokens / dt, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "reference bench.py: 256 seqs, prompts 100-1024 random tokens, 100-1024 new tokens "
+                                   "(133,966 output tokens), Qwen3-0.6B random-init, "
+                                   f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, hipGraph decode",
+                       "parallelism": f"tp{world}", "decode_steps": len(step_batches) // max(args.steps, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
