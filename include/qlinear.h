@@ -70,8 +70,11 @@ int ql_fake_quant(int dtype, int granularity, const void* w_bf16, int64_t N, int
 /* ---- fused dequant GEMMs ---------------------------------------------------------------- */
 
 /* Bytes of scratch the GEMM entry points need for an [M,N,K] problem with the configuration the
- * library would pick right now (split-K partial slabs; 0 when K is not split).  `granularity` is
- * the value that will be passed to ql_gemm_w8a16 (use QL_PER_ROW for ql_gemm_w8a8). */
+ * library would pick right now (64 KiB of per-tile ticket counters + split-K partial slabs; 0 when
+ * K is not split).  `granularity` is the value that will be passed to ql_gemm_w8a16 (use
+ * QL_PER_ROW for ql_gemm_w8a8).  The workspace must be ZERO-FILLED once when it is allocated: the
+ * first 64 KiB hold the counters, which every call leaves at zero again.  Calls that share a
+ * workspace must be ordered on one stream. */
 size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity);
 
 /* Weight-only forward: y[M,N] bf16 = x[M,K] bf16 . dequant(qw[N,K])^T (+ bias[N] bf16).
@@ -98,9 +101,11 @@ int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, con
 
 /* Tuning hook for benchmarks/tests: force the tile configuration of the next GEMM calls made by
  * this thread.  mt = 32-row fragments per wave (1,2,4,8), wn x wk = how the block's 4 waves split
- * N and K ((4,1),(2,2),(1,4)), split_k = K slices across workgroups.  Any argument <= 0 restores
- * the built-in heuristic for that field.  Returns QL_EINVAL for a combination that is not built. */
-int ql_gemm_force_config(int mt, int wn, int wk, int split_k);
+ * N and K ((4,1),(2,2),(1,4)), cp = 32-k steps a wave loads per chunk (2,4,8), split_k = K slices
+ * across workgroups.  mt = wn = wk = cp = 0 restores the built-in tile heuristic, split_k <= 0 the
+ * split heuristic.  Returns QL_EINVAL for a tile that is not built.  A forced split needs the
+ * workspace size that ql_gemm_workspace_bytes reports while the configuration is forced. */
+int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k);
 
 /* ---- operators between the quantized GEMMs of a decoder layer (one launch each) ------------- */
 

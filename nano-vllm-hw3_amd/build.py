@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nanovllm", "_lib")
 LIB = os.path.join(OUT_DIR, "libqlinear.so")
-SOURCES = ["ql_quant.hip", "ql_gemm.hip", "ql_ops.hip"]
+SOURCES = ["ql_quant.hip", "ql_gemm.hip", "ql_ops.hip", "ql_gemm_inst_bf16_i8_row.hip", "ql_gemm_inst_bf16_i8_group.hip",
+           "ql_gemm_inst_bf16_fp8_row.hip", "ql_gemm_inst_bf16_fp8_group.hip", "ql_gemm_inst_i8_i8.hip",
+           "ql_gemm_inst_fp8_fp8.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 
 
@@ -46,7 +48,7 @@ def build(force=False, verbose=True):
             subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

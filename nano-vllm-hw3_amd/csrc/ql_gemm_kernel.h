@@ -1,0 +1,408 @@
+// Fused dequant GEMM for gfx950:  y[M,N] = x[M,K] . dequant(qw[N,K])^T     (kernel templates)
+//
+// One kernel family covers decode (M <= 256, latency/HBM-bound on the 1-byte weight stream) and prefill.
+// Structure (per 256-thread workgroup = 4 waves, arranged WN x WK over N and K):
+//   * every wave owns a strip of 32 output columns and ALL rows of the block's M tile
+//     (MT fragments of 32 rows).  Its 1-byte weights go HBM -> VGPR directly (16 B per lane, no LDS:
+//     a weight byte is read by exactly one wave), are widened int8/fp8 -> bf16 in registers ONCE
+//     and reused for every row fragment, so the VALU cost of the dequant is amortised over MT MFMAs.
+//   * the activation tile (shared by the waves) is staged through LDS in 16-B pieces, XOR-swizzled so
+//     that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots of the 256-B bank row.
+//   * MFMA 32x32x16 (bf16 / fp8) or 32x32x32 (int8): A = activations (rows = m), B = weights
+//     (cols = n), f32 / i32 accumulators; lane l holds column n = l&31 and rows
+//     (r&3) + 8*(r>>2) + 4*(l>>5) of each 32x32 fragment.
+//   * a lane's 16 consecutive k of a weight row (one 16-B load) feed two K=16 MFMAs (bytes 0-7, 8-15);
+//     the activation fragment is read with the same k order, so the contraction is a permutation
+//     of the k sum and no byte shuffling is needed.
+//   * scales never touch the inner loop for per-row / per-tensor (applied to the f32 accumulator in
+//     the epilogue); per-group keeps a second accumulator per fragment that is folded into the
+//     running sum with its f32 group scale at each group boundary.
+//   * a K chunk of CP x 32 k per wave is loaded at once (CP x 16-B weight loads per lane in flight
+//     before the first wait); DB = LDS double buffer (next chunk's loads overlap this chunk's MFMAs),
+//     !DB = single buffer for problems whose K slice fits one chunk (everything in flight at once).
+//   * K can be split across the block's waves (WK, reduced through LDS in a fixed order) and across
+//     workgroups (blockIdx.z): each slice stores its f32/i32 partial tile to a slab, takes a ticket
+//     on a per-tile counter, and the LAST arriver sums the slabs in slice order and runs the epilogue
+//     (agent-scope release before the ticket, agent-scope acquire after it; no spinning, so no
+//     co-residency requirement).  Results are bit-reproducible run to run.
+#pragma once
+#include "ql_common.h"
+#include <type_traits>
+
+namespace ql {
+
+enum { ACT_BF16 = 0, ACT_I8 = 1, ACT_FP8 = 2 };
+
+constexpr int kCounterBytes = 64 * 1024;   // head of the workspace: one u32 ticket counter per output tile
+constexpr int kMaxTiles = kCounterBytes / 4;
+
+struct GemmParams {
+    const unsigned char* x;      // [M,K] bf16 (ACT_BF16) or 1-byte (ACT_I8 / ACT_FP8)
+    const unsigned char* w;      // [N,K] 1-byte
+    const float* sw;             // [N] | [1] | [N, K/group]
+    const float* sx;             // [M] for W8A8, else null
+    const unsigned short* bias;  // [N] bf16 or null
+    unsigned short* y;           // [M,N] bf16
+    unsigned* counters;          // [tiles] zero before the call, zero again after it (split-K only)
+    void* partial;               // [tiles][S][WN][MT][16][64] f32 / i32 slabs (split-K only)
+    int M, N, K;
+    int group;                   // group size (per-group only)
+    int sw_stride;               // 1 per-row, 0 per-tensor
+    int k_per_split;             // multiple of the block's K chunk
+    int bias_after_round;        // 1: bf16(bf16(v) + b)   0: bf16(v + b)
+};
+
+typedef void (*kern_t)(const GemmParams);
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
+    // {hi[31:16], lo[31:16]}: exact for values representable in bf16
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+
+// 8 one-byte weights (two dwords) -> 8 bf16 (exact: |int8| <= 128 and e4m3 both fit bf16's 8-bit significand)
+template <bool FP8W>
+__device__ __forceinline__ bf16x8 widen8(int d0, int d1) {
+    unsigned o[4];
+    if (FP8W) {
+        auto a = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false);
+        auto b = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
+        auto c = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false);
+        auto d = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
+        o[0] = pack_hi16(a[0], a[1]); o[1] = pack_hi16(b[0], b[1]);
+        o[2] = pack_hi16(c[0], c[1]); o[3] = pack_hi16(d[0], d[1]);
+    } else {
+        const int dd[2] = {d0, d1};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = dd[h];
+            const float f0 = (float)(int)(signed char)(d);
+            const float f1 = (float)(int)(signed char)(d >> 8);
+            const float f2 = (float)(int)(signed char)(d >> 16);
+            const float f3 = (float)(d >> 24);
+            o[2 * h] = pack_hi16(f0, f1);
+            o[2 * h + 1] = pack_hi16(f2, f3);
+        }
+    }
+    i32x4 v = {(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int RB>
+__device__ __forceinline__ int lds_off(int row, int ci) {
+    constexpr int CPR = RB / 16;                       // 16-byte pieces per row
+    constexpr int RPB = (RB >= 256) ? 1 : 256 / RB;    // rows per 256-byte bank row
+    constexpr int MASK = (CPR >= 16) ? 15 : CPR - 1;
+    const int f = (row / RPB) & MASK;
+    return row * RB + (((ci & ~MASK) | ((ci ^ f) & MASK)) << 4);
+}
+
+template <int ACT, int MT, int WN, int WK, int CP, bool DB>
+struct Cfg {
+    static constexpr int AB = (ACT == ACT_BF16) ? 2 : 1;          // activation bytes per element
+    static constexpr int BM = 32 * MT;
+    static constexpr int BN = 32 * WN;
+    static constexpr int KW = 32 * CP;                            // k per wave per chunk
+    static constexpr int KB = KW * WK;                            // k per block per chunk
+    static constexpr int RB = KB * AB;                            // LDS row bytes
+    static constexpr int CPR = RB / 16;
+    static constexpr int NP = BM * CPR / 256;                     // 16-B pieces staged per thread
+    static constexpr int XBYTES = BM * RB;
+    static constexpr int RED = (WK > 1) ? (WK - 1) * WN * MT * 16 * 64 * 4 : 0;
+    static constexpr int XALL = (DB ? 2 : 1) * XBYTES;
+    static constexpr int LDS = (XALL > RED) ? XALL : RED;
+    static_assert(WN * WK == 4, "4 waves per block");
+    static_assert(NP >= 1 && (BM * CPR) % 256 == 0, "staging must tile the block");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP>
+__global__ __launch_bounds__(256) void qgemm_kernel(const GemmParams p) {
+    using C = Cfg<ACT, MT, WN, WK, CP, DB>;
+    constexpr bool INT = (ACT == ACT_I8);
+    using acc_t = typename std::conditional<INT, i32x16, f32x16>::type;
+    using raw_t = typename std::conditional<INT, int, float>::type;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave % WN;
+    const int wk = wave / WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int m0 = blockIdx.y * C::BM;
+    const int n0 = blockIdx.x * C::BN + wn * 32;
+    const int k0 = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, k0 + p.k_per_split);
+    const int nchunks = (kend - k0 + C::KB - 1) / C::KB;
+
+    // this lane's weight row (clamped: out-of-range columns compute garbage that is never stored)
+    const int nrow = min(n0 + l31, p.N - 1);
+    const unsigned char* wrow = p.w + (size_t)nrow * p.K + wk * C::KW + 16 * lh;
+
+    acc_t acc[MT];
+    acc_t accg[GROUP ? MT : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+    if (GROUP) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accg[i][r] = 0;
+    }
+
+    i32x4 wcur[CP], wnext[DB ? CP : 1], sreg[C::NP];
+
+    auto load_w = [&](int kc, auto& dst) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            const int kb = kc + wk * C::KW + c * 32;
+            if (kb < kend) dst[c] = *(const i32x4*)(wrow + kc + c * 32);
+            else dst[c] = i32x4{0, 0, 0, 0};
+        }
+    };
+    auto load_x = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < C::NP; ++j) {
+            const int pidx = tid + 256 * j;
+            const int row = pidx / C::CPR, ci = pidx % C::CPR;
+            const int gm = m0 + row;
+            const int k = kc + ci * (16 / C::AB);
+            if (gm < p.M && k < kend)
+                sreg[j] = *(const i32x4*)(p.x + ((size_t)gm * p.K + k) * C::AB);
+            else
+                sreg[j] = i32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < C::NP; ++j) {
+            const int pidx = tid + 256 * j;
+            const int row = pidx / C::CPR, ci = pidx % C::CPR;
+            *(i32x4*)(smem + buf * C::XBYTES + lds_off<C::RB>(row, ci)) = sreg[j];
+        }
+    };
+    auto flush_group = [&](int kb) {
+        // fold the finished group's partial sums into the running sum with the group's f32 scale
+        const float s = p.sw[(size_t)nrow * (p.K / p.group) + kb / p.group];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][r] = __builtin_fmaf((float)accg[i][r], s, (float)acc[i][r]);
+                accg[i][r] = 0;
+            }
+    };
+    auto compute = [&](int buf, int kc, const i32x4 (&wr)[CP]) {
+        const unsigned char* xb = smem + buf * C::XBYTES;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            const int kb = kc + wk * C::KW + c * 32;   // first k of this pair-step (wave-uniform)
+            if (kb < kend) {
+                if (ACT == ACT_BF16) {
+                    const bf16x8 blo = widen8<FP8W>(wr[c][0], wr[c][1]);
+                    const bf16x8 bhi = widen8<FP8W>(wr[c][2], wr[c][3]);
+                    const int ci = (wk * CP + c) * 4 + 2 * lh;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int row = 32 * i + l31;
+                        const bf16x8 alo = *(const bf16x8*)(xb + lds_off<C::RB>(row, ci));
+                        const bf16x8 ahi = *(const bf16x8*)(xb + lds_off<C::RB>(row, ci + 1));
+                        if (GROUP) {
+                            accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, accg[i], 0, 0, 0);
+                            accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, accg[i], 0, 0, 0);
+                        } else {
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[i], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const int ci = (wk * CP + c) * 2 + lh;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int row = 32 * i + l31;
+                        const i32x4 a = *(const i32x4*)(xb + lds_off<C::RB>(row, ci));
+                        if constexpr (ACT == ACT_I8) {
+                            acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, wr[c], acc[i], 0, 0, 0);
+                        } else {
+                            const long a0 = ((long)(unsigned)a[1] << 32) | (unsigned)a[0];
+                            const long a1 = ((long)(unsigned)a[3] << 32) | (unsigned)a[2];
+                            const long b0 = ((long)(unsigned)wr[c][1] << 32) | (unsigned)wr[c][0];
+                            const long b1 = ((long)(unsigned)wr[c][3] << 32) | (unsigned)wr[c][2];
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+                if (GROUP) {
+                    // flush at every group end, and at the end of a wave chunk (the next chunk of this
+                    // wave may belong to another group, or continue this one: both are handled by
+                    // scaling what has been summed so far with the current group's scale)
+                    const int gq = (p.group < C::KW) ? p.group : C::KW;
+                    if (((kb + 32) % gq) == 0 || kb + 32 >= kend) flush_group(kb);
+                }
+            }
+        }
+    };
+
+    if constexpr (DB) {
+        // LDS double buffer for x, register double buffer for the weights
+        if (nchunks > 0) {
+            load_w(k0, wcur);
+            load_x(k0);
+            store_x(0);
+        }
+        __syncthreads();
+        for (int it = 0; it < nchunks; ++it) {
+            const int kc = k0 + it * C::KB;
+            const int buf = it & 1;
+            const bool more = (it + 1) < nchunks;
+            if (more) {
+                load_w(kc + C::KB, wnext);
+                load_x(kc + C::KB);
+            }
+            compute(buf, kc, wcur);
+            if (more) {
+                store_x(buf ^ 1);
+#pragma unroll
+                for (int c = 0; c < CP; ++c) wcur[c] = wnext[c];
+            }
+            __syncthreads();
+        }
+    } else {
+        // single buffer: the whole K slice is normally ONE chunk, every load of the block in flight at once
+        for (int it = 0; it < nchunks; ++it) {
+            const int kc = k0 + it * C::KB;
+            load_w(kc, wcur);
+            load_x(kc);
+            store_x(0);
+            __syncthreads();
+            compute(0, kc, wcur);
+            __syncthreads();
+        }
+    }
+
+    // ---- reduce the WK waves of a column strip through LDS (fixed order) ----------------------
+    if (WK > 1) {
+        raw_t* red = (raw_t*)smem;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[((((wk - 1) * WN + wn) * MT + i) * 16 + r) * 64 + lane] = acc[i][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int j = 1; j < WK; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][r] += red[((((j - 1) * WN + wn) * MT + i) * 16 + r) * 64 + lane];
+        }
+    }
+
+    // ---- split-K across workgroups: slab store, ticket, last arriver reduces -------------------
+    const int S = gridDim.z;
+    if (S > 1) {
+        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+        raw_t* slab = (raw_t*)p.partial + ((size_t)tile * S) * (WN * MT * 16 * 64);
+        if (wk == 0) {
+            raw_t* mine = slab + ((size_t)blockIdx.z * WN + wn) * (MT * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(i * 16 + r) * 64 + lane] = acc[i][r];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // also: every wave is done with smem
+        unsigned* flag = (unsigned*)smem;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = (t == (unsigned)(S - 1)) ? 1u : 0u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+            for (int s = 0; s < S; ++s) {
+                const raw_t* src = slab + ((size_t)s * WN + wn) * (MT * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] += src[(i * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (wk != 0) return;
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    const int n = n0 + l31;
+    if (n >= p.N) return;
+    float sw = 1.f, bias = 0.f;
+    if (!GROUP) sw = p.sw[(size_t)n * p.sw_stride];
+    if (p.bias) bias = bf16_bits_to_f32(p.bias[n]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < p.M) {
+                float v = (float)acc[i][r];
+                if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[m]);
+                v = __fmul_rn(v, sw);
+                if (p.bias) {
+                    if (p.bias_after_round) v = __fadd_rn(round_to_bf16(v), bias);
+                    else v = __fadd_rn(v, bias);
+                }
+                p.y[(size_t)m * p.N + n] = f32_to_bf16_bits(v);
+            }
+        }
+    }
+}
+
+// The tile configurations that are built: {MT, WN, WK, CP, DB}
+struct TileCfg { int mt, wn, wk, cp, db; };
+#define QL_TILE_LIST(X)                                                                              \
+    X(1, 1, 4, 2, true) X(1, 1, 4, 4, true) X(1, 1, 4, 8, false)                                     \
+    X(2, 1, 4, 2, true) X(2, 1, 4, 4, true)                                                          \
+    X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true)                                      \
+    X(2, 2, 2, 2, true) X(2, 2, 2, 4, true) X(2, 2, 2, 8, false)                                     \
+    X(4, 2, 2, 2, true) X(4, 2, 2, 4, true)
+#define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
+
+// one translation unit per arithmetic variant instantiates these
+template <int ACT, bool FP8W, bool GROUP>
+kern_t pick_kernel_impl(int mt, int wn, int wk, int cp) {
+#define QL_PICK(MT_, WN_, WK_, CP_, DB_) \
+    if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) return (kern_t)qgemm_kernel<ACT, FP8W, MT_, WN_, WK_, CP_, DB_, GROUP>;
+    QL_TILE_LIST(QL_PICK)
+    if constexpr (!GROUP) { QL_TILE_LIST_TALL(QL_PICK) }
+#undef QL_PICK
+    return nullptr;
+}
+
+kern_t pick_bf16_i8_row(int, int, int, int);
+kern_t pick_bf16_i8_group(int, int, int, int);
+kern_t pick_bf16_fp8_row(int, int, int, int);
+kern_t pick_bf16_fp8_group(int, int, int, int);
+kern_t pick_i8_i8(int, int, int, int);
+kern_t pick_fp8_fp8(int, int, int, int);
+
+}  // namespace ql

@@ -29,7 +29,7 @@ SIGNATURES = {
                                _c_int, _c_vp, _c_sz, _c_vp]),
     "ql_gemm_w8a8": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_vp, _c_sz, _c_vp]),
-    "ql_gemm_force_config": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "ql_gemm_force_config": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "ql_add_rmsnorm": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_silu_mul": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_qknorm_rope_store": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp,
@@ -106,7 +106,9 @@ class _Workspace:
                 raise QLinearError(
                     f"split-K workspace of {nbytes} bytes requested during graph capture; call "
                     "reserve_workspace() for the largest batch before capturing")
-            self.buf[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            # zero-filled: the head of the workspace holds the split-K ticket counters, which the
+            # kernels leave at zero after every call
+            self.buf[key] = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         return self.buf[key]
 
     def get(self, device, nbytes):

@@ -22,8 +22,16 @@ from nanovllm import _qlinear as Q
 _DTYPES = [torch.float8_e4m3fn, torch.int8]
 
 
+_scratch16 = {}
+
+
 def _ws16(device):
-    return Q.workspace.reserve(device, 16)
+    """16-byte scratch of the per-tensor quantizers (their global |max| word).  Deliberately NOT the
+    GEMM workspace: that one starts with the split-K ticket counters, which must stay zero."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _scratch16:
+        _scratch16[key] = torch.zeros(16, dtype=torch.uint8, device=device)
+    return _scratch16[key]
 
 
 # --------------------------------------------------------------------------- quantizers

@@ -51,10 +51,13 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ql_quant_per_group(0, one, 4, 256, 96, one, one, None) == -2
     assert lib.ql_quant_per_row(0, one, 4, 100, one, one, None) == -2
     assert lib.ql_gemm_w8a8(0, one, one, one, None, None, one, 4, 64, 128, None, 0, None) == -1
-    assert lib.ql_gemm_force_config(3, 4, 1, 0) == -1
-    assert lib.ql_gemm_force_config(0, 0, 0, 0) == 0
-    # workspace sizing is pure host arithmetic
-    assert lib.ql_gemm_workspace_bytes(256, 4096, 1024, 0) == 0 or lib.ql_gemm_workspace_bytes(256, 4096, 1024, 0) % (256 * 4096 * 4) == 0
+    assert lib.ql_gemm_force_config(3, 4, 1, 4, 0) == -1
+    assert lib.ql_gemm_force_config(0, 0, 0, 0, 0) == 0
+    # workspace sizing is pure host arithmetic: 64 KiB of counters + split x tile slabs, or nothing
+    assert lib.ql_gemm_force_config(1, 1, 4, 2, 4) == 0
+    assert lib.ql_gemm_workspace_bytes(16, 64, 2048, 0) == 65536 + 2 * 4 * (1 * 1 * 16 * 64 * 4)
+    assert lib.ql_gemm_force_config(0, 0, 0, 0, 0) == 0
+    assert lib.ql_gemm_workspace_bytes(4096, 4096, 1024, 0) == 0
 
 
 def test_ops_refuse_cpu_tensors():

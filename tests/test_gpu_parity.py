@@ -174,7 +174,8 @@ def test_w8a8_reference_selftest_tolerance(NQ):
 
 
 # ----------------------------------------------------------------------------- every tile / split
-TILES = [(1, 1, 4), (2, 1, 4), (1, 4, 1), (2, 4, 1), (4, 4, 1), (8, 4, 1), (2, 2, 2), (4, 2, 2)]
+TILES = [(1, 1, 4, 2), (1, 1, 4, 4), (1, 1, 4, 8), (2, 1, 4, 2), (2, 1, 4, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4),
+         (8, 4, 1, 4), (2, 2, 2, 2), (2, 2, 2, 4), (2, 2, 2, 8), (4, 2, 2, 2), (4, 2, 2, 4)]
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -188,9 +189,8 @@ def test_every_tile_configuration(NQ, tile, split):
     rng = np.random.default_rng(11)
     xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05)
     x = bf16_t(xb)
-    Q.workspace.reserve("cuda", 8 * M * N * 4)
     try:
-        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], split) == 0
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], split) == 0
         for dt in DTYPES:
             qo, so = O.per_row_quant(wb, dt)
             qw, sw = q_t(qo, dt), torch.from_numpy(so).cuda()
@@ -211,7 +211,7 @@ def test_every_tile_configuration(NQ, tile, split):
                 assert_gemm_close(bits16(yg), O.per_group_matmul(xb[:, :1152], qg, sg, None, g, dt, return_f64=True),
                                   O.abs_product_sum(xb[:, :1152], deq), what=f"group {dt} {tile}")
     finally:
-        lib.ql_gemm_force_config(0, 0, 0, 0)
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
 @pytest.mark.parametrize("g", [32, 64, 128, 256, 512])

@@ -22,7 +22,8 @@ SHAPES = {
     "4b": [("qkv", 6144, 2560), ("o", 2560, 4096), ("gate_up", 19456, 2560), ("down", 2560, 9728)],
     "8b_tp8": [("qkv", 768, 4096), ("o", 4096, 512), ("gate_up", 3072, 4096), ("down", 4096, 1536)],
 }
-TILES = [(1, 1, 4), (2, 1, 4), (1, 4, 1), (2, 4, 1), (4, 4, 1), (8, 4, 1), (2, 2, 2), (4, 2, 2)]
+TILES = [(1, 1, 4, 2), (1, 1, 4, 4), (1, 1, 4, 8), (2, 1, 4, 2), (2, 1, 4, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4),
+         (8, 4, 1, 4), (2, 2, 2, 2), (2, 2, 2, 4), (2, 2, 2, 8), (4, 2, 2, 2), (4, 2, 2, 4)]
 
 
 def time_fn(fn, n_copies, iters):
@@ -61,12 +62,17 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--out", default="")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--copies", type=int, default=0, help="weight copies cycled (0 = enough to defeat the 256 MiB cache)")
+    ap.add_argument("--shapes", default="", help="comma list of shape names to run")
     args = ap.parse_args()
     lib = Q.load()
     dev = "cuda"
     rows = []
     for name, N, K in SHAPES[args.model]:
-        n_copies = max(2, int(600e6 // (N * K)) + 1)
+        if args.shapes and name not in args.shapes.split(","):
+            continue
+        n_copies = args.copies if args.copies > 0 else max(2, int(600e6 // (N * K)) + 1)
         w = (torch.randn(n_copies, N, K, device=dev) * 0.02).to(torch.bfloat16) if args.mode == "bf16" else None
         dt = torch.float8_e4m3fn if args.mode == "w8a8fp8" else torch.int8
         if args.mode != "bf16":
@@ -78,7 +84,7 @@ def main():
             qw = q1.unsqueeze(0).repeat(n_copies, 1, 1).contiguous()
         for M in [int(m) for m in args.ms.split(",")]:
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
-            Q.workspace.reserve(dev, 64 * M * N * 4 if M <= 512 else 8 * M * N * 4)
+            Q.workspace.reserve(dev, 256 << 20)
             if args.mode == "w8a16":
                 fn = lambda i: NQ.per_row_weight_only_matmul(x, qw[i], s1, None, dt)
             elif args.mode == "group":
@@ -95,15 +101,15 @@ def main():
             best = None
             for cfg in cfgs:
                 if cfg is not None:
-                    (mt, wn, wk), sp = cfg
+                    (mt, wn, wk, cp), sp = cfg
                     if mt * 32 >= 2 * max(M, 32) and mt > 1:
                         continue
-                    kb = 32 * (2 if wk > 1 else 4) * wk
+                    kb = 32 * cp * wk
                     if sp > max(1, K // kb):
                         continue
-                    lib.ql_gemm_force_config(mt, wn, wk, sp)
+                    lib.ql_gemm_force_config(mt, wn, wk, cp, sp)
                 else:
-                    lib.ql_gemm_force_config(0, 0, 0, 0)
+                    lib.ql_gemm_force_config(0, 0, 0, 0, 0)
                 try:
                     us = time_fn(fn, n_copies, iters)
                 except Exception as ex:  # workspace too small for a forced split etc.
@@ -113,12 +119,12 @@ def main():
                 abytes = wbytes + 2 * M * K + 2 * M * N + 4 * N
                 rec = dict(shape=name, N=N, K=K, M=M, cfg=cfg, us=round(us, 2), GBps=round(abytes / us / 1e3, 1),
                            TFLOPs=round(2 * M * N * K / us / 1e6, 1))
-                if cfg is None:
+                if cfg is None or args.verbose:
                     rows.append(rec)
                     print(json.dumps(rec), flush=True)
                 if best is None or us < best["us"]:
                     best = rec
-            lib.ql_gemm_force_config(0, 0, 0, 0)
+            lib.ql_gemm_force_config(0, 0, 0, 0, 0)
             if args.sweep and best is not None:
                 best = dict(best, best=True)
                 rows.append(best)
