@@ -26,8 +26,19 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     // flight at once.  Prefill-sized problems use the tallest tile so that each weight byte is
     // converted once per 256 rows.
     int mt, wn, wk, cp;
-    if (M <= 256) { mt = 1; wn = 1; wk = 4; cp = 2; }
-    else { mt = group ? 4 : 8; wn = 4; wk = 1; cp = 4; }
+    int64_t split = 1;
+    if (M <= 256) {
+        mt = 1; wn = 1; wk = 4;
+        const int64_t base = ((M + 31) / 32) * ((N + 31) / 32);
+        // few tiles (N = hidden size, small batch): split K so that each slice is one 1024-k chunk
+        if (base < 128) split = (K + 1023) / 1024;
+        const int64_t kslice = (K + split - 1) / split;
+        if (M <= 64 || (kslice > 1024 && kslice <= 2048)) cp = 8;   // whole slice in flight at once
+        else if (kslice <= 1024) cp = 2;
+        else cp = 4;
+    } else {
+        mt = group ? 4 : 8; wn = 4; wk = 1; cp = 4;
+    }
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group)) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
     }
@@ -36,13 +47,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     const int64_t mblocks = (M + 32 * mt - 1) / (32 * mt);
     const int64_t nblocks = (N + 32 * wn - 1) / (32 * wn);
     const int64_t kchunks = (K + kb - 1) / kb;
-    // split K across workgroups only when the grid would leave most CUs idle, and keep >= 512 k per slice
-    int64_t split = 1;
     const int64_t base = mblocks * nblocks;
-    const int64_t max_split = K / 512 > 0 ? K / 512 : 1;
-    if (base < 128) split = (256 + base - 1) / base;
-    else if (base < 512 && K >= 2048) split = 2;
-    if (split > max_split) split = max_split;
     if (f_split > 0) split = f_split;
     if (split > 64) split = 64;
     if (split > kchunks) split = kchunks;
