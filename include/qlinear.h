@@ -132,11 +132,15 @@ int ql_qknorm_rope_store(const void* qkv_bf16, const int64_t* positions, const f
 /* Single-query attention over a paged KV cache: the decode half of Attention.forward
  * (nanovllm/layers/attention.py:59-75, flash_attn_with_kvcache there).  q/out [B,Hq,128];
  * caches [num_blocks, block_size, Hkv, 128]; block_tables [B, max_blocks]; context_lens [B]
- * (0 = padded row, output 0).  Hq/Hkv in {1,2,4}. */
+ * (0 = padded row, output 0).  Hq/Hkv in {1,2,4}.  One workgroup per (sequence, kv head, 512-token
+ * chunk); sequences longer than one chunk are merged by a second small launch through `workspace`
+ * (ql_paged_attn_workspace_bytes bytes, no initialisation needed; calls sharing it must be
+ * stream-ordered). */
+size_t ql_paged_attn_workspace_bytes(int64_t B, int Hq, int Hkv, int block_size, int max_blocks);
 int ql_paged_attn_decode(const void* q_bf16, const void* k_cache, const void* v_cache,
                          const int* block_tables, const int* context_lens, void* out_bf16, float scale,
                          int64_t B, int Hq, int Hkv, int head_dim, int block_size, int max_blocks,
-                         void* stream);
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

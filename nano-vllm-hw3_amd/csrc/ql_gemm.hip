@@ -89,7 +89,7 @@ static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_byte
         p.counters = (unsigned*)ws;
         p.partial = (unsigned char*)ws + kCounterBytes;
     }
-    hipLaunchKernelGGL(k, pl.grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k, pl.grid, dim3(64 * pl.wn * pl.wk), 0, s, p);
     QL_CHECK_LAUNCH(fn);
     return QL_OK;
 }

@@ -2,6 +2,7 @@
 //
 // One kernel family covers decode (M <= 256, latency/HBM-bound on the 1-byte weight stream) and prefill.
 // Structure (per 256-thread workgroup = 4 waves, arranged WN x WK over N and K):
+//   (workgroups of 8 waves, 512 threads, exist too: WN x WK = 8)
 //   * every wave owns a strip of 32 output columns and ALL rows of the block's M tile
 //     (MT fragments of 32 rows).  Its 1-byte weights go HBM -> VGPR directly (16 B per lane, no LDS:
 //     a weight byte is read by exactly one wave), are widened int8/fp8 -> bf16 in registers ONCE
@@ -105,18 +106,20 @@ struct Cfg {
     static constexpr int KB = KW * WK;                            // k per block per chunk
     static constexpr int RB = KB * AB;                            // LDS row bytes
     static constexpr int CPR = RB / 16;
-    static constexpr int NP = BM * CPR / 256;                     // 16-B pieces staged per thread
+    static constexpr int NW = WN * WK;                            // waves per workgroup (4 or 8)
+    static constexpr int NT = 64 * NW;                            // threads per workgroup
+    static constexpr int NP = BM * CPR / NT;                      // 16-B pieces staged per thread
     static constexpr int XBYTES = BM * RB;
     static constexpr int RED = (WK > 1) ? (WK - 1) * WN * MT * 16 * 64 * 4 : 0;
     static constexpr int XALL = (DB ? 2 : 1) * XBYTES;
     static constexpr int LDS = (XALL > RED) ? XALL : RED;
-    static_assert(WN * WK == 4, "4 waves per block");
-    static_assert(NP >= 1 && (BM * CPR) % 256 == 0, "staging must tile the block");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+    static_assert(NP >= 1 && (BM * CPR) % NT == 0, "staging must tile the block");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
 template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP>
-__global__ __launch_bounds__(256) void qgemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p) {
     using C = Cfg<ACT, MT, WN, WK, CP, DB>;
     constexpr bool INT = (ACT == ACT_I8);
     using acc_t = typename std::conditional<INT, i32x16, f32x16>::type;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(const GemmParams p) {
     auto load_x = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < C::NP; ++j) {
-            const int pidx = tid + 256 * j;
+            const int pidx = tid + C::NT * j;
             const int row = pidx / C::CPR, ci = pidx % C::CPR;
             const int gm = m0 + row;
             const int k = kc + ci * (16 / C::AB);
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(const GemmParams p) {
     auto store_x = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < C::NP; ++j) {
-            const int pidx = tid + 256 * j;
+            const int pidx = tid + C::NT * j;
             const int row = pidx / C::CPR, ci = pidx % C::CPR;
             *(i32x4*)(smem + buf * C::XBYTES + lds_off<C::RB>(row, ci)) = sreg[j];
         }
@@ -384,7 +387,9 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(2, 1, 4, 2, true) X(2, 1, 4, 4, true)                                                          \
     X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true)                                      \
     X(2, 2, 2, 2, true) X(2, 2, 2, 4, true) X(2, 2, 2, 8, false)                                     \
-    X(4, 2, 2, 2, true) X(4, 2, 2, 4, true)
+    X(4, 2, 2, 2, true) X(4, 2, 2, 4, true)                                                          \
+    X(1, 2, 4, 8, false) X(1, 2, 4, 4, true) X(2, 2, 4, 8, false) X(2, 2, 4, 4, true) X(1, 1, 8, 4, false)     \
+    X(2, 4, 2, 4, true) X(4, 4, 2, 4, true)
 #define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these

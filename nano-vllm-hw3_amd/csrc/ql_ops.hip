@@ -145,22 +145,34 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
 }
 
 // ---- decode attention over a paged KV cache ------------------------------------------------------
-// grid (batch, kv_head); the G = Hq/Hkv query heads of a kv head share every K/V byte that is read.
+// grid (batch, kv_head, chunk): one workgroup per chunk of CHUNK tokens of a sequence, so long and
+// short sequences load the chip evenly (a grid of one workgroup per sequence ends on its longest
+// sequence).  The G = Hq/Hkv query heads of a kv head share every K/V byte that is read.
 // A wave covers 4 tokens per step: lane = 16 * token_slot + dim_segment, one 16-byte (8 x bf16) load
-// of K and of V per lane and token.  Online softmax per token slot; the 16 slot states of the block
-// are merged through LDS at the end.
+// of K and of V per lane and token, 4 tokens per slot in flight.  Online softmax per token slot; the
+// 16 slot states of the workgroup are merged through LDS.  A sequence with more than one chunk
+// stores its per-chunk (max, sum, weighted V) state and a second, tiny launch merges the chunks in
+// order (an in-kernel merge behind agent-scope fences measured slower: one L2 write-back per chunk).
+constexpr int kAttnChunk = 512;
 template <int G>
 __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const unsigned short* __restrict__ q, const unsigned short* __restrict__ k_cache,
     const unsigned short* __restrict__ v_cache, const int* __restrict__ block_tables,
     const int* __restrict__ context_lens, unsigned short* __restrict__ out, float scale, int Hq, int Hkv,
-    int block_size, int max_blocks) {
+    int block_size, int max_blocks, int max_chunks, float* __restrict__ partial) {
     __shared__ float st_m[16][G], st_l[16][G];
     __shared__ float st_acc[16][G][128];
-    const int b = blockIdx.x, hk = blockIdx.y;
+    const int b = blockIdx.x, hk = blockIdx.y, sp = blockIdx.z;
+    const int ctx = context_lens[b];
+    const int nsp = (ctx + kAttnChunk - 1) / kAttnChunk;
+    if (ctx == 0) {
+        if (sp == 0)
+            for (int o = threadIdx.x; o < G * 128; o += 256) out[((size_t)b * Hq + hk * G) * 128 + o] = 0;
+        return;
+    }
+    if (sp >= nsp) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = lane >> 4, seg = lane & 15;
-    const int ctx = context_lens[b];
     float qv[G][8], acc[G][8], m[G], l[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -171,30 +183,41 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
         l[g] = 0.f;
     }
     const int* bt = block_tables + (size_t)b * max_blocks;
-    for (int t0 = wave * 4 + slot; t0 < ctx; t0 += 16) {
-        const int blk = bt[t0 / block_size];
-        const size_t off = (((size_t)blk * block_size + (t0 % block_size)) * Hkv + hk) * 128 + seg * 8;
-        const u16x8 kk = *(const u16x8*)(k_cache + off);
-        const u16x8 vv = *(const u16x8*)(v_cache + off);
-        float kf[8], vf[8];
+    const int tbeg = sp * kAttnChunk;
+    const int tend = min(ctx, tbeg + kAttnChunk);                 // tokens [tbeg, tend) of the sequence
+    const size_t hoff = (size_t)hk * 128 + seg * 8;
+    constexpr int U = 4;   // tokens per slot per iteration: 2*U 16-byte loads in flight per lane
+    for (int t0 = tbeg + wave * 4 + slot; t0 < tend; t0 += 16 * U) {
+        u16x8 kk[U], vv[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[j] = bf16_bits_to_f32(kk[j]); vf[j] = bf16_bits_to_f32(vv[j]); }
+        for (int u = 0; u < U; ++u) {
+            const int t = min(t0 + 16 * u, tend - 1);             // clamped: no divergent loads
+            const size_t off = ((size_t)bt[t / block_size] * block_size + (t % block_size)) * Hkv * 128 + hoff;
+            kk[u] = *(const u16x8*)(k_cache + off);
+            vv[u] = *(const u16x8*)(v_cache + off);
+        }
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float s = 0.f;
+        for (int u = 0; u < U; ++u) {
+            if (t0 + 16 * u < tend) {
+                float kf[8], vf[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += qv[g][j] * kf[j];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            const float mn = fmaxf(m[g], s);
-            const float alpha = __expf(m[g] - mn), pe = __expf(s - mn);
-            l[g] = l[g] * alpha + pe;
+                for (int j = 0; j < 8; ++j) { kf[j] = bf16_bits_to_f32(kk[u][j]); vf[j] = bf16_bits_to_f32(vv[u][j]); }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[g][j] = acc[g][j] * alpha + pe * vf[j];
-            m[g] = mn;
+                for (int g = 0; g < G; ++g) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += qv[g][j] * kf[j];
+                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                    const float mn = fmaxf(m[g], s);
+                    const float alpha = __expf(m[g] - mn), pe = __expf(s - mn);
+                    l[g] = l[g] * alpha + pe;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[g][j] = acc[g][j] * alpha + pe * vf[j];
+                    m[g] = mn;
+                }
+            }
         }
     }
-    // note: lanes whose token index ran past ctx simply did fewer iterations (no cross-lane op outside
-    // their own 16-lane token slot is used inside the loop)
     const int sidx = wave * 4 + slot;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -203,6 +226,8 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
         for (int j = 0; j < 8; ++j) st_acc[sidx][g][seg * 8 + j] = acc[g][j];
     }
     __syncthreads();
+    const size_t tile = (size_t)b * Hkv + hk;
+    float* mypart = partial + ((tile * max_chunks + sp) * G) * 130;
     for (int o = threadIdx.x; o < G * 128; o += 256) {
         const int g = o >> 7, d = o & 127;
         float mm = -1e30f;
@@ -215,7 +240,37 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
             num += wgt * st_acc[s][g][d];
             den += wgt * st_l[s][g];
         }
-        out[((size_t)b * Hq + hk * G + g) * 128 + d] = f32_to_bf16_bits(den > 0.f ? num / den : 0.f);
+        if (nsp == 1) {
+            out[((size_t)b * Hq + hk * G + g) * 128 + d] = f32_to_bf16_bits(num / den);
+        } else {
+            mypart[g * 130 + 2 + d] = num;
+            if (d == 0) { mypart[g * 130] = mm; mypart[g * 130 + 1] = den; }
+        }
+    }
+}
+
+// merge the per-chunk states of sequences longer than one chunk (grid (batch, kv_head))
+template <int G>
+__global__ __launch_bounds__(256) void paged_attn_combine_kernel(const int* __restrict__ context_lens,
+                                                                 const float* __restrict__ partial,
+                                                                 unsigned short* __restrict__ out, int Hq, int Hkv,
+                                                                 int max_chunks) {
+    const int b = blockIdx.x, hk = blockIdx.y;
+    const int nsp = (context_lens[b] + kAttnChunk - 1) / kAttnChunk;
+    if (nsp <= 1) return;
+    const float* parts = partial + (((size_t)b * Hkv + hk) * max_chunks) * G * 130;
+    for (int o = threadIdx.x; o < G * 128; o += 256) {
+        const int g = o >> 7, d = o & 127;
+        float mm = -1e30f;
+        for (int s = 0; s < nsp; ++s) mm = fmaxf(mm, parts[(s * G + g) * 130]);
+        float num = 0.f, den = 0.f;
+        for (int s = 0; s < nsp; ++s) {
+            const float* ps = parts + (s * G + g) * 130;
+            const float wgt = __expf(ps[0] - mm);
+            num += wgt * ps[2 + d];
+            den += wgt * ps[1];
+        }
+        out[((size_t)b * Hq + hk * G + g) * 128 + d] = f32_to_bf16_bits(num / den);
     }
 }
 
@@ -279,9 +334,16 @@ int ql_qknorm_rope_store(const void* qkv, const int64_t* positions, const float*
     return QL_OK;
 }
 
+size_t ql_paged_attn_workspace_bytes(int64_t B, int Hq, int Hkv, int block_size, int max_blocks) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || max_blocks <= 0 || block_size <= 0) return 0;
+    const size_t chunks = ((size_t)max_blocks * block_size + kAttnChunk - 1) / kAttnChunk;
+    if (chunks <= 1) return 0;
+    return (size_t)B * Hkv * chunks * (Hq / Hkv) * 130 * 4;
+}
+
 int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
                          const int* context_lens, void* out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
-                         int block_size, int max_blocks, void* stream) {
+                         int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream) {
     if (B < 0 || Hq <= 0 || Hkv <= 0 || block_size <= 0 || max_blocks <= 0 ||
         (B > 0 && (!q || !k_cache || !v_cache || !block_tables || !context_lens || !out))) {
         set_error("ql_paged_attn_decode: bad argument");
@@ -291,12 +353,24 @@ int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache
     const int G = Hq / Hkv;
     if (G != 1 && G != 2 && G != 4) { set_error("ql_paged_attn_decode: Hq/Hkv=%d not built (1,2,4)", G); return QL_ESHAPE; }
     if (B == 0) return QL_OK;
-    if (B > 0x7FFFFFFF || Hkv > 65535) { set_error("ql_paged_attn_decode: batch too large"); return QL_ESHAPE; }
-    dim3 grid((unsigned)B, (unsigned)Hkv), block(256);
+    const size_t chunks = ((size_t)max_blocks * block_size + kAttnChunk - 1) / kAttnChunk;
+    if (B > 0x7FFFFFFF || Hkv > 65535 || chunks > 65535) { set_error("ql_paged_attn_decode: batch too large"); return QL_ESHAPE; }
+    const size_t need = ql_paged_attn_workspace_bytes(B, Hq, Hkv, block_size, max_blocks);
+    if (need && (!workspace || workspace_bytes < need)) {
+        set_error("ql_paged_attn_decode: workspace of %zu bytes needed, got %zu", need, workspace_bytes);
+        return QL_EWORKSPACE;
+    }
+    dim3 grid((unsigned)B, (unsigned)Hkv, (unsigned)chunks), block(256);
     hipStream_t s = as_stream(stream);
-#define QL_ATT(G_) hipLaunchKernelGGL(paged_attn_decode_kernel<G_>, grid, block, 0, s, (const unsigned short*)q, \
-        (const unsigned short*)k_cache, (const unsigned short*)v_cache, block_tables, context_lens, (unsigned short*)out, \
-        scale, Hq, Hkv, block_size, max_blocks)
+#define QL_ATT(G_)                                                                                                  \
+    do {                                                                                                            \
+        hipLaunchKernelGGL(paged_attn_decode_kernel<G_>, grid, block, 0, s, (const unsigned short*)q,               \
+                           (const unsigned short*)k_cache, (const unsigned short*)v_cache, block_tables, context_lens, \
+                           (unsigned short*)out, scale, Hq, Hkv, block_size, max_blocks, (int)chunks, (float*)workspace); \
+        if (chunks > 1)                                                                                             \
+            hipLaunchKernelGGL(paged_attn_combine_kernel<G_>, dim3((unsigned)B, (unsigned)Hkv), block, 0, s,        \
+                               context_lens, (const float*)workspace, (unsigned short*)out, Hq, Hkv, (int)chunks);  \
+    } while (0)
     if (G == 1) QL_ATT(1); else if (G == 2) QL_ATT(2); else QL_ATT(4);
 #undef QL_ATT
     QL_CHECK_LAUNCH("ql_paged_attn_decode");

@@ -34,8 +34,9 @@ SIGNATURES = {
     "ql_silu_mul": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_qknorm_rope_store": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),
+    "ql_paged_attn_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
     "ql_paged_attn_decode": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64, _c_int, _c_int,
-                                      _c_int, _c_int, _c_int, _c_vp]),
+                                      _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
 }
 
 _lib = None
@@ -118,4 +119,5 @@ class _Workspace:
         return b.data_ptr(), b.numel()
 
 
-workspace = _Workspace()
+workspace = _Workspace()        # split-K slabs of the GEMMs
+attn_workspace = _Workspace()   # per-KV-block partial states of decode attention

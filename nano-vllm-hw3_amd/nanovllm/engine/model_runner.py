@@ -35,6 +35,10 @@ class ModelRunner:
             self._reserve_gemm_workspace()
             self.allocate_kv_cache()
             self.graphs = {}
+            from nanovllm import ops
+            ops.reserve_attn_workspace(min(config.max_num_seqs, 512), hf.num_attention_heads // self.world_size,
+                                       hf.num_key_value_heads // self.world_size, self.block_size,
+                                       (config.max_model_len + self.block_size - 1) // self.block_size, self.device)
             if not self.enforce_eager:
                 self.capture_graphs()
         finally:

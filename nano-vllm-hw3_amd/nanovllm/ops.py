@@ -54,13 +54,24 @@ def qknorm_rope_store(qkv, positions, cos_sin, q_norm_w, k_norm_w, eps, num_head
     return q, k, v
 
 
+def reserve_attn_workspace(max_batch, num_heads, num_kv_heads, block_size, max_blocks, device=None):
+    """Allocate the decode-attention workspace for the largest batch before graph capture."""
+    device = device if device is not None else torch.cuda.current_device()
+    n = Q.load().ql_paged_attn_workspace_bytes(max_batch, num_heads, num_kv_heads, block_size, max_blocks)
+    Q.attn_workspace.reserve(device, n)
+    return n
+
+
 def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale):
     """q [B,Hq,D]; caches [num_blocks, block_size, Hkv, D] -> out [B,Hq,D]."""
     Q.require_cuda(q, BF16, "q")
     B, Hq, D = q.shape
     _, block_size, Hkv, _ = k_cache.shape
     out = torch.empty_like(q)
-    Q.check(Q.load().ql_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
-                                          context_lens.data_ptr(), out.data_ptr(), scale, B, Hq, Hkv, D, block_size,
-                                          block_tables.shape[1], Q.stream_ptr(q.device)))
+    lib = Q.load()
+    max_blocks = block_tables.shape[1]
+    ws_ptr, ws_len = Q.attn_workspace.get(q.device, lib.ql_paged_attn_workspace_bytes(B, Hq, Hkv, block_size, max_blocks))
+    Q.check(lib.ql_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                     context_lens.data_ptr(), out.data_ptr(), scale, B, Hq, Hkv, D, block_size,
+                                     max_blocks, ws_ptr, ws_len, Q.stream_ptr(q.device)))
     return out

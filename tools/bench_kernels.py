@@ -23,7 +23,8 @@ SHAPES = {
     "8b_tp8": [("qkv", 768, 4096), ("o", 4096, 512), ("gate_up", 3072, 4096), ("down", 4096, 1536)],
 }
 TILES = [(1, 1, 4, 2), (1, 1, 4, 4), (1, 1, 4, 8), (2, 1, 4, 2), (2, 1, 4, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4),
-         (8, 4, 1, 4), (2, 2, 2, 2), (2, 2, 2, 4), (2, 2, 2, 8), (4, 2, 2, 2), (4, 2, 2, 4)]
+         (8, 4, 1, 4), (2, 2, 2, 2), (2, 2, 2, 4), (2, 2, 2, 8), (4, 2, 2, 2), (4, 2, 2, 4),
+         (1, 2, 4, 8), (1, 2, 4, 4), (2, 2, 4, 8), (2, 2, 4, 4), (1, 1, 8, 4), (2, 4, 2, 4), (4, 4, 2, 4)]
 
 
 def time_fn(fn, n_copies, iters):
