@@ -1,6 +1,7 @@
 // Host-side dispatch of the fused dequant GEMMs: tile selection, split-K planning, argument checks,
 // and the extern "C" entry points.  The kernels live in ql_gemm_kernel.h / ql_gemm_inst_*.hip.
 #include "ql_gemm_kernel.h"
+#include <stdlib.h>
 
 namespace ql {
 
@@ -70,7 +71,9 @@ static size_t plan_workspace(const Plan& pl) {
 static int check_common(const char* fn, int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N <= 0 || K <= 0) { set_error("%s: bad shape M=%lld N=%lld K=%lld", fn, (long long)M, (long long)N, (long long)K); return QL_EINVAL; }
     if (K % 32) { set_error("%s: K=%lld must be a multiple of 32", fn, (long long)K); return QL_ESHAPE; }
-    if (M > 0x3FFFFFFF || N > 0x3FFFFFFF || K > 0x3FFFFFFF || (M + 255) / 32 > 65535) {
+    // the kernels address weights and activations with 32-bit byte offsets from a uniform base
+    if (M > 0x3FFFFFFF || N > 0x3FFFFFFF || K > 0x3FFFFFFF || (M + 255) / 32 > 65535 ||
+        (uint64_t)N * (uint64_t)K >= (1ull << 32) || (uint64_t)(M + 256) * (uint64_t)K * 2 >= (1ull << 32)) {
         set_error("%s: shape too large", fn);
         return QL_ESHAPE;
     }

@@ -122,13 +122,22 @@ template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROU
 __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p) {
     using C = Cfg<ACT, MT, WN, WK, CP, DB>;
     constexpr bool INT = (ACT == ACT_I8);
+    constexpr int RB = C::RB;
+    constexpr int SWZ_RPB = (RB >= 256) ? 1 : 256 / RB;
+    constexpr int SWZ_MASK = (C::CPR >= 16) ? 15 : C::CPR - 1;
+    constexpr int APS = (ACT == ACT_BF16) ? 4 : 2;               // 16-B activation pieces per 32-k step and row
     using acc_t = typename std::conditional<INT, i32x16, f32x16>::type;
     using raw_t = typename std::conditional<INT, int, float>::type;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+    using TrueT = std::integral_constant<bool, true>;
+    using FalseT = std::integral_constant<bool, false>;
+    __shared__ __attribute__((aligned(128))) unsigned char smem[C::LDS];   // base must be a multiple of 32 (address ^ 16 below)
 
+    // The kernel is VALU-issue-bound at decode sizes, so everything that is uniform per wave is kept
+    // in scalar registers (the wave index is made provably uniform) and every per-lane address is
+    // split into a lane-constant part computed once and a uniform part.
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN;
     const int wk = wave / WN;
     const int l31 = lane & 31;
@@ -139,10 +148,25 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     const int k0 = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, k0 + p.k_per_split);
     const int nchunks = (kend - k0 + C::KB - 1) / C::KB;
+    const bool fullM = (m0 + C::BM <= p.M);
 
     // this lane's weight row (clamped: out-of-range columns compute garbage that is never stored)
     const int nrow = min(n0 + l31, p.N - 1);
-    const unsigned char* wrow = p.w + (size_t)nrow * p.K + wk * C::KW + 16 * lh;
+    const unsigned woff = (unsigned)nrow * (unsigned)p.K + (unsigned)(16 * lh);   // + uniform k offset per load
+
+    // activation staging: thread t moves piece ci = t % CPR of rows row0 + j * RS (j < NP)
+    static_assert(C::NT % C::CPR == 0 || C::CPR % C::NT == 0, "staging pattern");
+    constexpr int RS = (C::NT >= C::CPR) ? C::NT / C::CPR : 1;   // row step between a thread's pieces
+    static_assert(C::NT >= C::CPR, "a row's pieces must not outnumber the threads");
+    const int st_ci = tid % C::CPR;
+    const int st_row0 = tid / C::CPR;
+    const unsigned xoff0 = ((unsigned)(m0 + st_row0) * (unsigned)p.K) * C::AB + (unsigned)st_ci * 16u;
+    const int st_k = st_ci * (16 / C::AB);                        // k of this thread's piece inside a chunk
+
+    // A-fragment reads: row 32*i + l31; the XOR swizzle only involves lane-constant bits
+    const int a_g4 = ((((l31 / SWZ_RPB) & SWZ_MASK) ^ (ACT == ACT_BF16 ? 2 * lh : lh)) & SWZ_MASK) << 4;
+    const int a_hi = (ACT == ACT_BF16 ? 2 * lh : lh) & ~SWZ_MASK;   // 0 unless a row has < 4 pieces (never)
+    const int a_row = l31 * RB + (a_hi << 4);
 
     acc_t acc[MT];
     acc_t accg[GROUP ? MT : 1];
@@ -157,36 +181,37 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             for (int r = 0; r < 16; ++r) accg[i][r] = 0;
     }
 
-    i32x4 wcur[CP], wnext[DB ? CP : 1], sreg[C::NP];
+    constexpr int D = DB ? CP : (CP < 8 ? CP : 8);               // weight loads in flight per lane
+    i32x4 wcur[D], wnext[DB ? CP : 1], sreg[C::NP];
 
-    auto load_w = [&](int kc, auto& dst) {
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            const int kb = kc + wk * C::KW + c * 32;
-            if (kb < kend) dst[c] = *(const i32x4*)(wrow + kc + c * 32);
-            else dst[c] = i32x4{0, 0, 0, 0};
-        }
+    // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
+    auto load_w1 = [&](auto chk, int kc, int c) -> i32x4 {
+        const int kb = kc + wk * C::KW + c * 32;
+        if (!decltype(chk)::value || kb < kend) return *(const i32x4*)(p.w + kb + woff);
+        return i32x4{0, 0, 0, 0};
     };
-    auto load_x = [&](int kc) {
+    auto load_x = [&](auto chk, int kc) {
+        if (fullM) {
+            const bool ok = !decltype(chk)::value || (kc + st_k < kend);
+            const unsigned off = ok ? xoff0 : (unsigned)(m0 * p.K) * C::AB;      // any valid address when past the slice
+            const unsigned char* xs = p.x + (size_t)kc * C::AB;
 #pragma unroll
-        for (int j = 0; j < C::NP; ++j) {
-            const int pidx = tid + C::NT * j;
-            const int row = pidx / C::CPR, ci = pidx % C::CPR;
-            const int gm = m0 + row;
-            const int k = kc + ci * (16 / C::AB);
-            if (gm < p.M && k < kend)
+            for (int j = 0; j < C::NP; ++j)
+                sreg[j] = *(const i32x4*)(xs + (size_t)j * RS * p.K * C::AB + off);
+        } else {
+            // last row block: rows past M re-read row M-1 (their outputs are never stored)
+#pragma unroll
+            for (int j = 0; j < C::NP; ++j) {
+                const int gm = min(m0 + st_row0 + j * RS, p.M - 1);
+                const int k = (kc + st_k < kend) ? kc + st_k : k0;
                 sreg[j] = *(const i32x4*)(p.x + ((size_t)gm * p.K + k) * C::AB);
-            else
-                sreg[j] = i32x4{0, 0, 0, 0};
+            }
         }
     };
     auto store_x = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < C::NP; ++j) {
-            const int pidx = tid + C::NT * j;
-            const int row = pidx / C::CPR, ci = pidx % C::CPR;
-            *(i32x4*)(smem + buf * C::XBYTES + lds_off<C::RB>(row, ci)) = sreg[j];
-        }
+        for (int j = 0; j < C::NP; ++j)
+            *(i32x4*)(smem + buf * C::XBYTES + lds_off<RB>(st_row0 + j * RS, st_ci)) = sreg[j];
     };
     auto flush_group = [&](int kb) {
         // fold the finished group's partial sums into the running sum with the group's f32 scale
@@ -199,92 +224,112 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
                 accg[i][r] = 0;
             }
     };
-    auto compute = [&](int buf, int kc, const i32x4 (&wr)[CP]) {
-        const unsigned char* xb = smem + buf * C::XBYTES;
+    // one 32-k step of this wave: widen the 16 weight bytes of the lane, MT x (A fragment reads + MFMAs)
+    auto step = [&](auto chk, int buf, int kc, int c, const i32x4 w) {
+        const int kb = kc + wk * C::KW + c * 32;   // first k of this step (wave-uniform)
+        if (decltype(chk)::value && kb >= kend) return;
+        const int base_c = (wk * CP + c) * APS;    // first piece of the step in an LDS row (uniform)
+        // piece index (base_c | lane part) with the low bits XOR-swizzled by the row
+        const unsigned char* a0 = smem + buf * C::XBYTES + a_row + ((base_c & ~SWZ_MASK) << 4) +
+                                  (((base_c & SWZ_MASK) << 4) ^ a_g4);
+        if constexpr (ACT == ACT_BF16) {
+            const bf16x8 blo = widen8<FP8W>(w[0], w[1]);
+            const bf16x8 bhi = widen8<FP8W>(w[2], w[3]);
+            const unsigned char* a1 = (const unsigned char*)((uintptr_t)a0 ^ 16);   // piece index + 1 == ^1 (index is even)
 #pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            const int kb = kc + wk * C::KW + c * 32;   // first k of this pair-step (wave-uniform)
-            if (kb < kend) {
-                if (ACT == ACT_BF16) {
-                    const bf16x8 blo = widen8<FP8W>(wr[c][0], wr[c][1]);
-                    const bf16x8 bhi = widen8<FP8W>(wr[c][2], wr[c][3]);
-                    const int ci = (wk * CP + c) * 4 + 2 * lh;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const int row = 32 * i + l31;
-                        const bf16x8 alo = *(const bf16x8*)(xb + lds_off<C::RB>(row, ci));
-                        const bf16x8 ahi = *(const bf16x8*)(xb + lds_off<C::RB>(row, ci + 1));
-                        if (GROUP) {
-                            accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, accg[i], 0, 0, 0);
-                            accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, accg[i], 0, 0, 0);
-                        } else {
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, acc[i], 0, 0, 0);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[i], 0, 0, 0);
-                        }
-                    }
-                } else {
-                    const int ci = (wk * CP + c) * 2 + lh;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const int row = 32 * i + l31;
-                        const i32x4 a = *(const i32x4*)(xb + lds_off<C::RB>(row, ci));
-                        if constexpr (ACT == ACT_I8) {
-                            acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, wr[c], acc[i], 0, 0, 0);
-                        } else {
-                            const long a0 = ((long)(unsigned)a[1] << 32) | (unsigned)a[0];
-                            const long a1 = ((long)(unsigned)a[3] << 32) | (unsigned)a[2];
-                            const long b0 = ((long)(unsigned)wr[c][1] << 32) | (unsigned)wr[c][0];
-                            const long b1 = ((long)(unsigned)wr[c][3] << 32) | (unsigned)wr[c][2];
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[i], 0, 0, 0);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[i], 0, 0, 0);
-                        }
-                    }
-                }
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8 alo = *(const bf16x8*)(a0 + i * 32 * RB);
+                const bf16x8 ahi = *(const bf16x8*)(a1 + i * 32 * RB);
                 if (GROUP) {
-                    // flush at every group end, and at the end of a wave chunk (the next chunk of this
-                    // wave may belong to another group, or continue this one: both are handled by
-                    // scaling what has been summed so far with the current group's scale)
-                    const int gq = (p.group < C::KW) ? p.group : C::KW;
-                    if (((kb + 32) % gq) == 0 || kb + 32 >= kend) flush_group(kb);
+                    accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, accg[i], 0, 0, 0);
+                    accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, accg[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[i], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const i32x4 a = *(const i32x4*)(a0 + i * 32 * RB);
+                if constexpr (ACT == ACT_I8) {
+                    acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, acc[i], 0, 0, 0);
+                } else {
+                    const long a0l = ((long)(unsigned)a[1] << 32) | (unsigned)a[0];
+                    const long a1l = ((long)(unsigned)a[3] << 32) | (unsigned)a[2];
+                    const long b0 = ((long)(unsigned)w[1] << 32) | (unsigned)w[0];
+                    const long b1 = ((long)(unsigned)w[3] << 32) | (unsigned)w[2];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0l, b0, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1l, b1, acc[i], 0, 0, 0);
                 }
             }
         }
+        if (GROUP) {
+            // flush at every group end, and at the end of a wave chunk (the next chunk of this
+            // wave may belong to another group, or continue this one: both are handled by
+            // scaling what has been summed so far with the current group's scale)
+            const int gq = (p.group < C::KW) ? p.group : C::KW;
+            if (((kb + 32) % gq) == 0 || kb + 32 >= kend) flush_group(kb);
+        }
+    };
+
+    // one chunk, CHK = the slice may end inside this chunk (per-step bounds tests needed)
+    auto chunk_db = [&](auto chk, int it) {
+        const int kc = k0 + it * C::KB;
+        const int buf = it & 1;
+        const bool more = (it + 1) < nchunks;
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) wnext[c] = load_w1(TrueT{}, kc + C::KB, c);
+            load_x(TrueT{}, kc + C::KB);
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) step(chk, buf, kc, c, wcur[c]);
+        if (more) {
+            store_x(buf ^ 1);
+#pragma unroll
+            for (int c = 0; c < CP; ++c) wcur[c] = wnext[c];
+        }
+        __syncthreads();
+    };
+    auto chunk_sb = [&](auto chk, int it) {
+        const int kc = k0 + it * C::KB;
+#pragma unroll
+        for (int j = 0; j < D; ++j) wcur[j] = load_w1(chk, kc, j);
+        load_x(chk, kc);
+        store_x(0);
+        __syncthreads();
+        for (int c0 = 0; c0 < CP; c0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const i32x4 w = wcur[j];
+                if (c0 + D + j < CP) wcur[j] = load_w1(chk, kc, c0 + D + j);
+                step(chk, 0, kc, c0 + j, w);
+            }
+        }
+        __syncthreads();
     };
 
     if constexpr (DB) {
         // LDS double buffer for x, register double buffer for the weights
         if (nchunks > 0) {
-            load_w(k0, wcur);
-            load_x(k0);
+#pragma unroll
+            for (int c = 0; c < CP; ++c) wcur[c] = load_w1(TrueT{}, k0, c);
+            load_x(TrueT{}, k0);
             store_x(0);
         }
         __syncthreads();
         for (int it = 0; it < nchunks; ++it) {
-            const int kc = k0 + it * C::KB;
-            const int buf = it & 1;
-            const bool more = (it + 1) < nchunks;
-            if (more) {
-                load_w(kc + C::KB, wnext);
-                load_x(kc + C::KB);
-            }
-            compute(buf, kc, wcur);
-            if (more) {
-                store_x(buf ^ 1);
-#pragma unroll
-                for (int c = 0; c < CP; ++c) wcur[c] = wnext[c];
-            }
-            __syncthreads();
+            if (k0 + (it + 1) * C::KB <= kend) chunk_db(FalseT{}, it);
+            else chunk_db(TrueT{}, it);
         }
     } else {
-        // single buffer: the whole K slice is normally ONE chunk, every load of the block in flight at once
+        // single buffer: the activation tile of the whole K slice (normally ONE chunk) is resident in
+        // LDS; after the one staging barrier every wave streams its weights through a register ring
+        // of D loads in flight and never synchronises with the other waves again
         for (int it = 0; it < nchunks; ++it) {
-            const int kc = k0 + it * C::KB;
-            load_w(kc, wcur);
-            load_x(kc);
-            store_x(0);
-            __syncthreads();
-            compute(0, kc, wcur);
-            __syncthreads();
+            if (k0 + (it + 1) * C::KB <= kend) chunk_sb(FalseT{}, it);
+            else chunk_sb(TrueT{}, it);
         }
     }
 
@@ -355,29 +400,35 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     }
     if (wk != 0) return;
 
-    // ---- epilogue ------------------------------------------------------------------------------
+    // ---- epilogue: scale (+ bias), one hardware RTNE conversion, 2-byte store per element -------
     const int n = n0 + l31;
     if (n >= p.N) return;
     float sw = 1.f, bias = 0.f;
     if (!GROUP) sw = p.sw[(size_t)n * p.sw_stride];
-    if (p.bias) bias = bf16_bits_to_f32(p.bias[n]);
+    const bool has_bias = p.bias != nullptr;
+    if (has_bias) bias = bf16_bits_to_f32(p.bias[n]);
+    const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.N + (unsigned)n;   // within the block's rows
+    auto emit = [&](auto chk) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m < p.M) {
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);                // uniform part of the row
+                if (decltype(chk)::value && m0 + rowc + 4 * lh >= p.M) continue;
                 float v = (float)acc[i][r];
-                if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[m]);
+                if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[m0 + rowc + 4 * lh]);
                 v = __fmul_rn(v, sw);
-                if (p.bias) {
-                    if (p.bias_after_round) v = __fadd_rn(round_to_bf16(v), bias);
+                if (has_bias) {
+                    if (p.bias_after_round) v = __fadd_rn((float)(bf16_t)v, bias);
                     else v = __fadd_rn(v, bias);
                 }
-                p.y[(size_t)m * p.N + n] = f32_to_bf16_bits(v);
+                unsigned short* yrow = p.y + (size_t)(m0 + rowc) * p.N;          // uniform pointer
+                yrow[lane_off] = __builtin_bit_cast(unsigned short, (bf16_t)v);
             }
         }
-    }
+    };
+    if (fullM) emit(FalseT{});
+    else emit(TrueT{});
 }
 
 // The tile configurations that are built: {MT, WN, WK, CP, DB}
@@ -389,8 +440,9 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(2, 2, 2, 2, true) X(2, 2, 2, 4, true) X(2, 2, 2, 8, false)                                     \
     X(4, 2, 2, 2, true) X(4, 2, 2, 4, true)                                                          \
     X(1, 2, 4, 8, false) X(1, 2, 4, 4, true) X(2, 2, 4, 8, false) X(2, 2, 4, 4, true) X(1, 1, 8, 4, false)     \
-    X(2, 4, 2, 4, true) X(4, 4, 2, 4, true)
-#define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
+    X(2, 4, 2, 4, true) X(4, 4, 2, 4, true)                                                          \
+    X(1, 4, 1, 32, false) X(1, 4, 2, 16, false) X(2, 4, 2, 16, false) X(1, 2, 4, 16, false) X(1, 1, 8, 8, false)
+#define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true) X(8, 8, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these
 template <int ACT, bool FP8W, bool GROUP>
