@@ -63,9 +63,8 @@ def measure_decode_gemm(llm, step_batches):
     mods = [[l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj] for l in layers]
     if not isinstance(mods[0][0], QLinear):
         return None
-    stream = torch.cuda.current_stream()
     tot_t = tot_b = tot_n = 0.0
-    busy = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
     with torch.inference_mode():
         for M, cnt in sorted(buckets.items()):
             xs = [torch.randn(M, m.qw.shape[1], device="cuda", dtype=torch.bfloat16) for m in mods[0]]
@@ -73,24 +72,35 @@ def measure_decode_gemm(llm, step_batches):
                 for x, m in zip(xs, m4):
                     m(x)
             torch.cuda.synchronize()
-            # keep the GPU busy while the host enqueues the bracketed launches, so that each event pair
-            # times the kernel(s) of one linear call and not the host's launch latency; the busy GEMMs
-            # also flush L2 / Infinity Cache, so the weights stream from HBM as they do in the real step
-            for _ in range(8):
-                torch.mm(busy, busy)
-            evs = []
-            for m4 in mods:
-                for x, m in zip(xs, m4):
+            # the 112 linear calls of one decode step at this batch bucket, captured into a hipGraph on
+            # a side stream (as the real decode step is) and timed with HIP events recorded on that
+            # stream around the replay: per-launch time = elapsed / launches.  It contains the ~1.5-2 us
+            # dependent-launch gap, exactly as each launch costs inside the decode graph; rocprofv3's
+            # per-kernel duration excludes that gap.
+            g = torch.cuda.CUDAGraph()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    for m4 in mods:
+                        for x, m in zip(xs, m4):
+                            m(x)
+                nbytes = sum(gemm_bytes(M, m.qw.shape[0], m.qw.shape[1]) for m4 in mods for m in m4)
+                nlaunch = sum(len(m4) for m4 in mods)
+                g.replay()
+                side.synchronize()
+                best = None
+                for _ in range(3):
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s.record(stream)
-                    m(x)
-                    e.record(stream)
-                    evs.append((s, e, gemm_bytes(M, m.qw.shape[0], m.qw.shape[1])))
-            torch.cuda.synchronize()
-            for s, e, b in evs:
-                tot_t += s.elapsed_time(e) * 1e-3 * cnt
-                tot_b += b * cnt
-                tot_n += cnt
+                    s.record(side)
+                    g.replay()
+                    e.record(side)
+                    side.synchronize()
+                    t = s.elapsed_time(e) * 1e-3
+                    best = t if best is None else min(best, t)
+            del g
+            tot_t += best * cnt
+            tot_b += nbytes * cnt
+            tot_n += nlaunch * cnt
     if tot_n == 0:
         return None
     avg_us = tot_t / tot_n * 1e6

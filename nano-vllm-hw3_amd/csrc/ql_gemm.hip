@@ -22,24 +22,29 @@ struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; };
 
 static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     Plan pl;
-    // Decode-sized problems (M <= 256) are latency/L2-bound, not MFMA-bound, on a 256-CU chip: the
-    // measured optimum is many small workgroups at high occupancy with every load of a K slice in
-    // flight at once.  Prefill-sized problems use the tallest tile so that each weight byte is
-    // converted once per 256 rows.
-    int mt, wn, wk, cp;
-    int64_t split = 1;
-    if (M <= 256) {
-        mt = 1; wn = 1; wk = 4;
-        const int64_t base = ((M + 31) / 32) * ((N + 31) / 32);
-        // few tiles (N = hidden size, small batch): split K so that each slice is one 1024-k chunk
-        if (base < 128) split = (K + 1023) / 1024;
-        const int64_t kslice = (K + split - 1) / split;
-        if (M <= 64 || (kslice > 1024 && kslice <= 2048)) cp = 8;   // whole slice in flight at once
-        else if (kslice <= 1024) cp = 2;
-        else cp = 4;
-    } else {
-        mt = group ? 4 : 8; wn = 4; wk = 1; cp = 4;
+    // Tile ladder, smallest to largest output tile.  On a 256-CU chip these GEMMs are bound by
+    // instruction issue and L2->LDS traffic per workgroup, not by HBM or MFMA peak, so the measured
+    // optimum (tools/bench_kernels.py --sweep) is the LARGEST tile that still yields about one
+    // workgroup per CU: bigger tiles re-read less of x and w through L2 and amortise the int8->bf16
+    // widening over more rows, smaller tiles only win while the grid would otherwise leave CUs idle.
+    static const TileCfg ladder[] = {
+        {1, 1, 8, 4, 0},    //  32 x  32, 8 waves split K, x resident in LDS
+        {1, 2, 4, 8, 0},    //  32 x  64
+        {2, 2, 4, 8, 0},    //  64 x  64
+        {2, 4, 2, 4, 1},    //  64 x 128
+    };
+    const int nladder = (int)(sizeof(ladder) / sizeof(ladder[0]));
+    int pick = 0;
+    for (int i = 0; i < nladder; ++i) {
+        const TileCfg& t = ladder[i];
+        if (group && t.mt == 8) break;
+        const int64_t blocks = ((M + 32 * t.mt - 1) / (32 * t.mt)) * ((N + 32 * t.wn - 1) / (32 * t.wn));
+        if (blocks >= 160) pick = i;
     }
+    int mt = ladder[pick].mt, wn = ladder[pick].wn, wk = ladder[pick].wk, cp = ladder[pick].cp;
+    // prefill-sized problems: thousands of 64 x 128 tiles; four waves each running the whole K with
+    // the double-buffered pipeline measured best (the taller tiles lose occupancy to registers)
+    if (M > 1024) { mt = 2; wn = 4; wk = 1; cp = 4; }
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group)) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
     }
@@ -49,6 +54,10 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     const int64_t nblocks = (N + 32 * wn - 1) / (32 * wn);
     const int64_t kchunks = (K + kb - 1) / kb;
     const int64_t base = mblocks * nblocks;
+    // few tiles even at 32 x 32 (N = hidden size, small batch): split K so that each slice is one
+    // 1024-k chunk, combined in-kernel by the last arriver
+    int64_t split = 1;
+    if (base < 64) split = (K + 1023) / 1024;
     if (f_split > 0) split = f_split;
     if (split > 64) split = 64;
     if (split > kchunks) split = kchunks;

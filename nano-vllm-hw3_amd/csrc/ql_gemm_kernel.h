@@ -442,7 +442,7 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(1, 2, 4, 8, false) X(1, 2, 4, 4, true) X(2, 2, 4, 8, false) X(2, 2, 4, 4, true) X(1, 1, 8, 4, false)     \
     X(2, 4, 2, 4, true) X(4, 4, 2, 4, true)                                                          \
     X(1, 4, 1, 32, false) X(1, 4, 2, 16, false) X(2, 4, 2, 16, false) X(1, 2, 4, 16, false) X(1, 1, 8, 8, false)
-#define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true) X(8, 8, 1, 4, true)
+#define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these
 template <int ACT, bool FP8W, bool GROUP>
