@@ -29,7 +29,8 @@ class LLMEngine:
                     f"tensor_parallel_size={config.tensor_parallel_size} needs that many ranks "
                     f"(torch.distributed.run), got WORLD_SIZE={world}")
                 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
-                dist.init_process_group("nccl", rank=rank, world_size=world)
+                # "nccl" is RCCL on ROCm; NANOVLLM_DIST_BACKEND=gloo lets two ranks share one GPU in tests
+                dist.init_process_group(os.environ.get("NANOVLLM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
             self.rank = dist.get_rank()
         self.config = config
         self.model_runner = ModelRunner(config, self.rank)

@@ -26,7 +26,7 @@ class ModelRunner:
         try:
             self.model = Qwen3ForCausalLM(hf)
             if config.load_format == "dummy":
-                init_dummy_weights(self.model, seed=rank)
+                init_dummy_weights(self.model, hf, seed=0)
             else:
                 load_model(self.model, config.model)
             # quantization happens after loading, before warm-up and graph capture (reference:
@@ -40,7 +40,16 @@ class ModelRunner:
                                        hf.num_key_value_heads // self.world_size, self.block_size,
                                        (config.max_model_len + self.block_size - 1) // self.block_size, self.device)
             if not self.enforce_eager:
-                self.capture_graphs()
+                try:
+                    self.capture_graphs()
+                except Exception as ex:   # e.g. a collective that cannot be captured on this RCCL build
+                    if self.world_size == 1:
+                        raise
+                    import warnings
+                    warnings.warn(f"hipGraph capture failed under tensor parallelism ({ex!r}); decoding eagerly")
+                    self.graphs = {}
+                    self.enforce_eager = True
+                    torch.cuda.synchronize()
         finally:
             torch.set_default_device("cpu")
             torch.set_default_dtype(default_dtype)
