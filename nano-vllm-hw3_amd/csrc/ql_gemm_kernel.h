@@ -441,7 +441,8 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(4, 2, 2, 2, true) X(4, 2, 2, 4, true)                                                          \
     X(1, 2, 4, 8, false) X(1, 2, 4, 4, true) X(2, 2, 4, 8, false) X(2, 2, 4, 4, true) X(1, 1, 8, 4, false)     \
     X(2, 4, 2, 4, true) X(4, 4, 2, 4, true)                                                          \
-    X(1, 4, 1, 32, false) X(1, 4, 2, 16, false) X(2, 4, 2, 16, false) X(1, 2, 4, 16, false) X(1, 1, 8, 8, false)
+    X(1, 4, 1, 32, false) X(1, 4, 2, 16, false) X(2, 4, 2, 16, false) X(1, 2, 4, 16, false) X(1, 1, 8, 8, false) \
+    X(4, 8, 1, 2, true)
 #define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these

@@ -153,7 +153,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
 // 16 slot states of the workgroup are merged through LDS.  A sequence with more than one chunk
 // stores its per-chunk (max, sum, weighted V) state and a second, tiny launch merges the chunks in
 // order (an in-kernel merge behind agent-scope fences measured slower: one L2 write-back per chunk).
-constexpr int kAttnChunk = 512;
+#ifndef QL_ATTN_CHUNK
+#define QL_ATTN_CHUNK 512
+#endif
+#ifndef QL_ATTN_U
+#define QL_ATTN_U 4
+#endif
+constexpr int kAttnChunk = QL_ATTN_CHUNK;
 template <int G>
 __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const unsigned short* __restrict__ q, const unsigned short* __restrict__ k_cache,
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const int tbeg = sp * kAttnChunk;
     const int tend = min(ctx, tbeg + kAttnChunk);                 // tokens [tbeg, tend) of the sequence
     const size_t hoff = (size_t)hk * 128 + seg * 8;
-    constexpr int U = 4;   // tokens per slot per iteration: 2*U 16-byte loads in flight per lane
+    constexpr int U = QL_ATTN_U;   // tokens per slot per iteration: 2*U 16-byte loads in flight per lane
     for (int t0 = tbeg + wave * 4 + slot; t0 < tend; t0 += 16 * U) {
         u16x8 kk[U], vv[U];
 #pragma unroll

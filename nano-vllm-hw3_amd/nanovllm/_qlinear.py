@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libqlinear.so")
+LIB_PATH = os.environ.get("QLINEAR_LIB") or os.path.join(_HERE, "_lib", "libqlinear.so")   # env override: A/B builds
 
 QL_INT8, QL_FP8 = 0, 1
 QL_PER_ROW, QL_PER_TENSOR, QL_PER_GROUP = 0, 1, 2
