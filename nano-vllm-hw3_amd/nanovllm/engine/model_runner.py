@@ -39,6 +39,8 @@ class ModelRunner:
             ops.reserve_attn_workspace(min(config.max_num_seqs, 512), hf.num_attention_heads // self.world_size,
                                        hf.num_key_value_heads // self.world_size, self.block_size,
                                        (config.max_model_len + self.block_size - 1) // self.block_size, self.device)
+            self._init_decode_staging(min(config.max_num_seqs, 512),
+                                      (config.max_model_len + self.block_size - 1) // self.block_size)
             if not self.enforce_eager:
                 try:
                     self.capture_graphs()
@@ -91,6 +93,8 @@ class ModelRunner:
 
     def prepare_prefill(self, seqs):
         input_ids, positions, slot_mapping, cu = [], [], [], [0]
+        # (re)prefilled sequences may own different blocks than the decode staging rows remember
+        self._stage_rows = [None] * self._stage_max_bs
         for seq in seqs:
             n = len(seq)
             input_ids.extend(seq.token_ids)
@@ -107,7 +111,61 @@ class ModelRunner:
         set_context(AttnContext(is_prefill=True, cu_seqlens=cu, slot_mapping=slot))
         return self._dev(input_ids, torch.int64), self._dev(positions, torch.int64), cu
 
+    def _init_decode_staging(self, max_bs, max_blocks):
+        """All per-step decode inputs live in ONE int32 device buffer (ids and positions as int64 pairs,
+        slot mapping, context lengths, block tables) mirrored by one pinned host buffer: a decode step
+        costs a single host-to-device copy and no fill or scatter launches.  The hipGraph inputs are
+        views of the device buffer."""
+        words = max_bs * (2 + 2 + 1 + 1 + max_blocks)
+        self._stage_host = torch.zeros(words, dtype=torch.int32, device="cpu", pin_memory=True)
+        self._stage_dev = torch.zeros(words, dtype=torch.int32, device=self.device)
+
+        def views(buf):
+            o = 0
+            ids = buf[o:o + 2 * max_bs].view(torch.int64); o += 2 * max_bs
+            pos = buf[o:o + 2 * max_bs].view(torch.int64); o += 2 * max_bs
+            slots = buf[o:o + max_bs]; o += max_bs
+            ctx = buf[o:o + max_bs]; o += max_bs
+            tables = buf[o:o + max_bs * max_blocks].view(max_bs, max_blocks)
+            return ids, pos, slots, ctx, tables
+        self._stage_max_bs, self._stage_max_blocks = max_bs, max_blocks
+        self._hv = tuple(v.numpy() for v in views(self._stage_host))
+        self._dv = views(self._stage_dev)
+        self._hv[2].fill(-1)
+        self._stage_rows = [None] * max_bs          # (seq_id, len(block_table)) whose table each row holds
+        self._stage_prev_bs = 0
+
     def prepare_decode(self, seqs):
+        """Fills the pinned mirror and issues the one copy; returns device views of the first len(seqs)
+        rows.  Rows past the batch keep slot -1 / context 0 (what a padded graph bucket needs)."""
+        bs = len(seqs)
+        if bs > self._stage_max_bs or max(len(s.block_table) for s in seqs) > self._stage_max_blocks:
+            return self._prepare_decode_unstaged(seqs)
+        h_ids, h_pos, h_slots, h_ctx, h_tab = self._hv
+        bsz = self.block_size
+        lens = [len(s) for s in seqs]
+        h_ids[:bs] = [s.last_token for s in seqs]
+        h_ctx[:bs] = lens
+        h_pos[:bs] = h_ctx[:bs]
+        h_pos[:bs] -= 1
+        h_slots[:bs] = [s.block_table[-1] * bsz + (n - 1) % bsz for s, n in zip(seqs, lens)]
+        prev = self._stage_prev_bs
+        if prev > bs:
+            h_slots[bs:prev] = -1
+            h_ctx[bs:prev] = 0
+        self._stage_prev_bs = bs
+        rows = self._stage_rows
+        for i, s in enumerate(seqs):
+            bt = s.block_table
+            key = (s.seq_id, len(bt))
+            if rows[i] != key:
+                rows[i] = key
+                h_tab[i, :len(bt)] = bt
+        self._stage_dev.copy_(self._stage_host, non_blocking=True)
+        d = self._dv
+        return d[0][:bs], d[1][:bs], d[2][:bs], d[3][:bs], d[4][:bs]
+
+    def _prepare_decode_unstaged(self, seqs):
         input_ids = [s.last_token for s in seqs]
         positions = [len(s) - 1 for s in seqs]
         context_lens = [len(s) for s in seqs]
@@ -135,13 +193,6 @@ class ModelRunner:
             else:
                 gbs = next(x for x in self.graph_bs if x >= bs)
                 gv = self.graph_vars
-                gv["input_ids"][:bs] = ids
-                gv["positions"][:bs] = pos
-                gv["slot_mapping"].fill_(-1)
-                gv["slot_mapping"][:bs] = slots
-                gv["context_lens"].zero_()
-                gv["context_lens"][:bs] = ctx_lens
-                gv["block_tables"][:bs, :tables.shape[1]] = tables
                 self.graphs[gbs].replay()
                 logits = gv["logits"][:bs]
         token_ids = logits.argmax(dim=-1).tolist()     # greedy sampler (layers/sampler.py:10-12)
@@ -153,14 +204,10 @@ class ModelRunner:
         max_bs = min(cfg.max_num_seqs, 512)
         self.max_graph_bs = max_bs
         max_blocks = (cfg.max_model_len + self.block_size - 1) // self.block_size
-        gv = dict(
-            input_ids=torch.zeros(max_bs, dtype=torch.int64),
-            positions=torch.zeros(max_bs, dtype=torch.int64),
-            slot_mapping=torch.full((max_bs,), -1, dtype=torch.int32),
-            context_lens=torch.zeros(max_bs, dtype=torch.int32),
-            block_tables=torch.zeros(max_bs, max_blocks, dtype=torch.int32),
-            logits=torch.zeros(max_bs, hf.vocab_size),
-        )
+        d = self._dv
+        assert self._stage_max_bs >= max_bs and self._stage_max_blocks >= max_blocks
+        gv = dict(input_ids=d[0], positions=d[1], slot_mapping=d[2], context_lens=d[3], block_tables=d[4],
+                  logits=torch.zeros(max_bs, hf.vocab_size))
         self.graph_bs = [1, 2, 4, 8] + list(range(16, max_bs + 1, 16))
         pool = None
         for bs in reversed(self.graph_bs):
