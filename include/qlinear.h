@@ -99,6 +99,20 @@ int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, con
                  const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Gate/up projection with the SiLU-and-multiply of the MLP fused into the GEMM epilogue
+ * (Qwen3MLP.forward, nanovllm/models/qwen3.py:116-118 = gate_up_proj then SiluAndMul,
+ * nanovllm/layers/activation.py:11-14):  y[M, N/2] bf16 = silu(g) * u with g, u the bf16-rounded
+ * outputs ql_gemm_w8a16 / ql_gemm_w8a8 would have stored, so the result is bit-identical to the
+ * GEMM followed by ql_silu_mul.  The weight must be PRE-ARRANGED by the caller: with I = N/2 and the
+ * usual packed rows (gate rows [0,I), up rows [I,2I)), row 64*s + j of qw (and of sw / the group
+ * scales / bias) holds gate row 32*s + j for j < 32 and up row 32*s + j - 32 for j >= 32.
+ * Requires N % 64 == 0; never splits K across workgroups, so no workspace. */
+int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
+                       const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
+                       void* stream);
+int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
+                      const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, void* stream);
+
 /* Tuning hook for benchmarks/tests: force the tile configuration of the next GEMM calls made by
  * this thread.  mt = 32-row fragments per wave (1,2,4,8), wn x wk = how the block's 4 waves split
  * N and K ((4,1),(2,2),(1,4)), cp = 32-k steps a wave loads per chunk (2,4,8), split_k = K slices

@@ -66,6 +66,13 @@ __device__ __forceinline__ float e4m3fn_to_f32(unsigned char b) {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) | s);
 }
 
+// bf16(silu(g) * u) on bf16-representable inputs: one definition shared by the stand-alone operator
+// and the fused GEMM epilogue, so both produce the same bits (hardware reciprocal and conversion)
+__device__ __forceinline__ unsigned short silu_mul_bf16(float g, float u) {
+    const float s = g * __builtin_amdgcn_rcpf(1.f + __expf(-g));
+    return __builtin_bit_cast(unsigned short, (bf16_t)(s * u));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -20,7 +20,7 @@ static bool tile_built(int mt, int wn, int wk, int cp, bool group) {
 
 struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; };
 
-static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
+static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false) {
     Plan pl;
     // Tile ladder, smallest to largest output tile.  On a 256-CU chip these GEMMs are bound by
     // instruction issue and L2->LDS traffic per workgroup, not by HBM or MFMA peak, so the measured
@@ -34,8 +34,8 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
         {2, 4, 2, 4, 1},    //  64 x 128
     };
     const int nladder = (int)(sizeof(ladder) / sizeof(ladder[0]));
-    int pick = 0;
-    for (int i = 0; i < nladder; ++i) {
+    int pick = silu ? 1 : 0;                               // the fused SiLU epilogue pairs two column strips (WN >= 2)
+    for (int i = pick; i < nladder; ++i) {
         const TileCfg& t = ladder[i];
         if (group && t.mt == 8) break;
         const int64_t blocks = ((M + 32 * t.mt - 1) / (32 * t.mt)) * ((N + 32 * t.wn - 1) / (32 * t.wn));
@@ -50,7 +50,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
         // per MFMA (measured +25 % at M = 16384)
         if (!group && ((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = 2; }
     }
-    if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group)) {
+    if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group) && !(silu && (f_wn & 1))) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
     }
     pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
@@ -64,6 +64,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group) {
     int64_t split = 1;
     if (base < 64) split = (K + 1023) / 1024;
     if (f_split > 0) split = f_split;
+    if (silu) split = 1;                                    // gate and up meet in the epilogue of ONE workgroup
     if (split > 64) split = 64;
     if (split > kchunks) split = kchunks;
     if (base > kMaxTiles) split = 1;                        // one ticket counter per output tile
@@ -136,10 +137,9 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
     return QL_OK;
 }
 
-int ql_gemm_w8a16(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
-                  void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace, size_t workspace_bytes,
-                  void* stream) {
-    const char* fn = "ql_gemm_w8a16";
+static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, const void* x, const void* qw,
+                      const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group,
+                      void* workspace, size_t workspace_bytes, void* stream) {
     if ((wdtype != QL_INT8 && wdtype != QL_FP8) || granularity < QL_PER_ROW || granularity > QL_PER_GROUP ||
         (M > 0 && (!x || !y)) || !qw || !sw) {
         set_error("%s: bad argument (wdtype=%d granularity=%d)", fn, wdtype, granularity);
@@ -147,6 +147,7 @@ int ql_gemm_w8a16(int wdtype, int granularity, const void* x, const void* qw, co
     }
     int rc = check_common(fn, M, N, K);
     if (rc) return rc;
+    if (silu && N % 64) { set_error("%s: N=%lld must be a multiple of 64 (32-row gate/up strips)", fn, (long long)N); return QL_ESHAPE; }
     const bool grp = granularity == QL_PER_GROUP;
     if (grp) {
         const bool ok = group >= 32 && K % group == 0 && ((group % 128) == 0 || (128 % group) == 0);
@@ -159,30 +160,56 @@ int ql_gemm_w8a16(int wdtype, int granularity, const void* x, const void* qw, co
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = grp ? group : 0;
     p.sw_stride = granularity == QL_PER_ROW ? 1 : 0;
     p.bias_after_round = granularity == QL_PER_ROW ? 0 : 1;
-    const Plan pl = make_plan(M, N, K, grp);
+    p.silu = silu ? 1 : 0;
+    const Plan pl = make_plan(M, N, K, grp, silu);
     kern_t k;
     if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp);
     else k = grp ? pick_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
 
-int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
-                 void* y, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
-    const char* fn = "ql_gemm_w8a8";
+static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const float* sx, const void* qw,
+                     const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, void* workspace,
+                     size_t workspace_bytes, void* stream) {
     if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || !sx || !y)) || !qw || !sw) {
         set_error("%s: bad argument (dtype=%d)", fn, dtype);
         return QL_EINVAL;
     }
     int rc = check_common(fn, M, N, K);
     if (rc) return rc;
+    if (silu && N % 64) { set_error("%s: N=%lld must be a multiple of 64 (32-row gate/up strips)", fn, (long long)N); return QL_ESHAPE; }
     if (M == 0) return QL_OK;
     GemmParams p{};
     p.x = (const unsigned char*)qx; p.w = (const unsigned char*)qw; p.sw = sw; p.sx = sx;
     p.bias = (const unsigned short*)bias; p.y = (unsigned short*)y; p.partial = nullptr; p.counters = nullptr;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = 0; p.sw_stride = 1; p.bias_after_round = 0;
-    const Plan pl = make_plan(M, N, K, false);
+    p.silu = silu ? 1 : 0;
+    const Plan pl = make_plan(M, N, K, false, silu);
     kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
+}
+
+int ql_gemm_w8a16(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
+                  void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    return gemm_w8a16("ql_gemm_w8a16", false, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, workspace,
+                      workspace_bytes, stream);
+}
+
+int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
+                       void* y, int64_t M, int64_t N, int64_t K, int group, void* stream) {
+    return gemm_w8a16("ql_gemm_w8a16_silu", true, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, nullptr, 0,
+                      stream);
+}
+
+int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
+                 void* y, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_w8a8("ql_gemm_w8a8", false, dtype, qx, sx, qw, sw, bias, y, M, N, K, workspace, workspace_bytes, stream);
+}
+
+int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
+                      void* y, int64_t M, int64_t N, int64_t K, void* stream) {
+    return gemm_w8a8("ql_gemm_w8a8_silu", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -51,6 +51,7 @@ struct GemmParams {
     int sw_stride;               // 1 per-row, 0 per-tensor
     int k_per_split;             // multiple of the block's K chunk
     int bias_after_round;        // 1: bf16(bf16(v) + b)   0: bf16(v + b)
+    int silu;                    // 1: weight rows alternate 32-row strips of gate and up; y[M, N/2] = silu(gate) * up
 };
 
 typedef void (*kern_t)(const GemmParams);
@@ -110,9 +111,11 @@ struct Cfg {
     static constexpr int NT = 64 * NW;                            // threads per workgroup
     static constexpr int NP = BM * CPR / NT;                      // 16-B pieces staged per thread
     static constexpr int XBYTES = BM * RB;
-    static constexpr int RED = (WK > 1) ? (WK - 1) * WN * MT * 16 * 64 * 4 : 0;
+    static constexpr int RED = (WK > 1) ? WK * WN * MT * 16 * 64 * 4 : 0;       // K reduction across the block's waves
     static constexpr int XALL = (DB ? 2 : 1) * XBYTES;
-    static constexpr int LDS = (XALL > RED) ? XALL : RED;
+    static constexpr int PAIR = (WN >= 2) ? WK * (WN / 2) * MT * 16 * 64 * 2 : 0;   // gate/up exchange of the SiLU epilogue
+    static constexpr int LDS0 = (XALL > RED) ? XALL : RED;
+    static constexpr int LDS = (LDS0 > PAIR) ? LDS0 : PAIR;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(NP >= 1 && (BM * CPR) % NT == 0, "staging must tile the block");
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -333,102 +336,169 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         }
     }
 
-    // ---- reduce the WK waves of a column strip through LDS (fixed order) ----------------------
-    if (WK > 1) {
-        raw_t* red = (raw_t*)smem;
-        if (wk > 0) {
+    // ---- tail: K reduction, split-K hand-over and epilogue, spread over ALL waves of the block ----
+    // After the reduction wave wk of a strip owns accumulator registers [wk*RN, wk*RN + RN) of every
+    // fragment, i.e. 8*RN/4 ... rows of each 32-row fragment, so the slab traffic, the scaling and the
+    // stores are done by WK times more lanes than if wave 0 kept the whole tile.  Register indices must
+    // be compile-time constants, hence one instantiation of the tail per wk.
+    constexpr int RN = 16 / WK;
+    const int S = gridDim.z;
+    const int n = n0 + l31;
+    const bool nvalid = n < p.N;
+    float sw = 1.f, bias = 0.f;
+    if (!GROUP && nvalid) sw = p.sw[(size_t)n * p.sw_stride];
+    const bool has_bias = p.bias != nullptr;
+    if (has_bias && nvalid) bias = bf16_bits_to_f32(p.bias[n]);
+
+    auto tail = [&](auto wkc) {
+        constexpr int WKC = decltype(wkc)::value;
+        constexpr int R0 = WKC * RN;
+        if constexpr (WK > 1) {
+            // every wave parks the registers it does not own; the owner sums the WK partials in wave order
+            raw_t* red = (raw_t*)smem + (size_t)wn * (MT * 16 * 64) + lane;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    red[((((wk - 1) * WN + wn) * MT + i) * 16 + r) * 64 + lane] = acc[i][r];
-        }
-        __syncthreads();
-        if (wk == 0) {
-#pragma unroll
-            for (int j = 1; j < WK; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[i][r] += red[((((j - 1) * WN + wn) * MT + i) * 16 + r) * 64 + lane];
-        }
-    }
-
-    // ---- split-K across workgroups: slab store, ticket, last arriver reduces -------------------
-    const int S = gridDim.z;
-    if (S > 1) {
-        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
-        raw_t* slab = (raw_t*)p.partial + ((size_t)tile * S) * (WN * MT * 16 * 64);
-        if (wk == 0) {
-            raw_t* mine = slab + ((size_t)blockIdx.z * WN + wn) * (MT * 16 * 64);
+                    if (r < R0 || r >= R0 + RN) red[((WKC * WN * MT + i) * 16 + r) * 64] = acc[i][r];
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mine[(i * 16 + r) * 64 + lane] = acc[i][r];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                  // also: every wave is done with smem
-        unsigned* flag = (unsigned*)smem;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned t = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned last = (t == (unsigned)(S - 1)) ? 1u : 0u;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            *flag = last;
-        }
-        __syncthreads();
-        if (*flag == 0u) return;
-        if (wk == 0) {
+                for (int rr = 0; rr < RN; ++rr) {
+                    raw_t sum = 0;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0;
-            for (int s = 0; s < S; ++s) {
-                const raw_t* src = slab + ((size_t)s * WN + wn) * (MT * 16 * 64);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][r] += src[(i * 16 + r) * 64 + lane];
-            }
-        }
-    }
-    if (wk != 0) return;
-
-    // ---- epilogue: scale (+ bias), one hardware RTNE conversion, 2-byte store per element -------
-    const int n = n0 + l31;
-    if (n >= p.N) return;
-    float sw = 1.f, bias = 0.f;
-    if (!GROUP) sw = p.sw[(size_t)n * p.sw_stride];
-    const bool has_bias = p.bias != nullptr;
-    if (has_bias) bias = bf16_bits_to_f32(p.bias[n]);
-    const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.N + (unsigned)n;   // within the block's rows
-    auto emit = [&](auto chk) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);                // uniform part of the row
-                if (decltype(chk)::value && m0 + rowc + 4 * lh >= p.M) continue;
-                float v = (float)acc[i][r];
-                if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[m0 + rowc + 4 * lh]);
-                v = __fmul_rn(v, sw);
-                if (has_bias) {
-                    if (p.bias_after_round) v = __fadd_rn((float)(bf16_t)v, bias);
-                    else v = __fadd_rn(v, bias);
+                    for (int j = 0; j < WK; ++j)
+                        sum += (j == WKC) ? acc[i][R0 + rr] : red[((j * WN * MT + i) * 16 + R0 + rr) * 64];
+                    acc[i][R0 + rr] = sum;
                 }
-                unsigned short* yrow = p.y + (size_t)(m0 + rowc) * p.N;          // uniform pointer
-                yrow[lane_off] = __builtin_bit_cast(unsigned short, (bf16_t)v);
+        }
+        if (S > 1) {
+            // split-K across workgroups: slab store, ticket, the last arriver sums the slabs in slice order
+            const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+            raw_t* slab = (raw_t*)p.partial + ((size_t)tile * S) * (WN * MT * 16 * 64) + (size_t)wn * (MT * 16 * 64) + lane;
+            raw_t* mine = slab + (size_t)blockIdx.z * (WN * MT * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int rr = 0; rr < RN; ++rr) mine[(i * 16 + R0 + rr) * 64] = acc[i][R0 + rr];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // also: every wave is done with smem
+            unsigned* flag = (unsigned*)smem;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned t = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned last = (t == (unsigned)(S - 1)) ? 1u : 0u;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag == 0u) return;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int rr = 0; rr < RN; ++rr) acc[i][R0 + rr] = 0;
+            for (int s = 0; s < S; ++s) {
+                const raw_t* src = slab + (size_t)s * (WN * MT * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < RN; ++rr) acc[i][R0 + rr] += src[(i * 16 + R0 + rr) * 64];
             }
         }
+
+        // epilogue: scale (+ bias), one hardware RTNE conversion, 2-byte store per element
+        // element (fragment i, register r) of this lane as the bf16 the plain GEMM stores
+        auto outv = [&](int i, int r, int rowc) -> bf16_t {
+            float v = (float)acc[i][r];
+            if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[min(m0 + rowc + 4 * lh, p.M - 1)]);
+            v = __fmul_rn(v, sw);
+            if (has_bias) {
+                if (p.bias_after_round) v = __fadd_rn((float)(bf16_t)v, bias);
+                else v = __fadd_rn(v, bias);
+            }
+            return (bf16_t)v;
+        };
+        if (p.silu) {
+            // Fused SiLU * mul: strip 2s of the (pre-arranged) weight holds gate columns [32s, 32s+32),
+            // strip 2s+1 the matching up columns, so waves wn and wn^1 hold gate and up of the same
+            // output elements in the same lanes.  Each of the two finishes half of the pair's owned
+            // registers and gets the other operand of that half through LDS.
+            if constexpr (WN >= 2) {
+                constexpr int RH = RN / 2;
+                __syncthreads();                              // every wave is done with the x tile / reduce area
+                unsigned short* ex = (unsigned short*)smem + (size_t)((WKC * (WN / 2) + (wn >> 1)) * MT) * (16 * 64) + lane;
+                const unsigned I = (unsigned)p.N >> 1;
+                const unsigned col = (unsigned)((blockIdx.x * WN + wn) >> 1) * 32u + (unsigned)l31;
+                const unsigned lane_off = (unsigned)(4 * lh) * I + col;
+                // the gate wave finishes registers [R0, R0+RH), the up wave [R0+RH, R0+RN)
+                auto pair = [&](auto upc) {
+                    constexpr bool UP = decltype(upc)::value;
+                    constexpr int RMINE = R0 + (UP ? RH : 0), ROTHER = R0 + (UP ? 0 : RH);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int rr = 0; rr < RH; ++rr) {
+                            const int r = ROTHER + rr;
+                            ex[(i * 16 + r) * 64] = __builtin_bit_cast(unsigned short, outv(i, r, 32 * i + (r & 3) + 8 * (r >> 2)));
+                        }
+                    __syncthreads();
+                    if (!nvalid) return;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int rr = 0; rr < RH; ++rr) {
+                            const int r = RMINE + rr;
+                            const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);
+                            if (!fullM && m0 + rowc + 4 * lh >= p.M) continue;
+                            const float own = (float)outv(i, r, rowc);
+                            const float oth = bf16_bits_to_f32(ex[(i * 16 + r) * 64]);
+                            unsigned short* yrow = p.y + (size_t)(m0 + rowc) * I;
+                            yrow[lane_off] = UP ? silu_mul_bf16(oth, own) : silu_mul_bf16(own, oth);
+                        }
+                };
+                if (wn & 1) pair(TrueT{});
+                else pair(FalseT{});
+            }
+            return;
+        }
+        if (!nvalid) return;
+        const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.N + (unsigned)n;   // within the block's rows
+        auto emit = [&](auto chk) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int rr = 0; rr < RN; ++rr) {
+                    const int r = R0 + rr;
+                    const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);                // uniform part of the row
+                    if (decltype(chk)::value && m0 + rowc + 4 * lh >= p.M) continue;
+                    unsigned short* yrow = p.y + (size_t)(m0 + rowc) * p.N;          // uniform pointer
+                    yrow[lane_off] = __builtin_bit_cast(unsigned short, outv(i, r, rowc));
+                }
+            }
+        };
+        if (fullM) emit(FalseT{});
+        else emit(TrueT{});
     };
-    if (fullM) emit(FalseT{});
-    else emit(TrueT{});
+    if constexpr (WK == 1) {
+        tail(std::integral_constant<int, 0>{});
+    } else {
+        switch (wk) {
+            case 0: tail(std::integral_constant<int, 0>{}); break;
+            case 1: tail(std::integral_constant<int, 1>{}); break;
+            case 2: if constexpr (WK > 2) tail(std::integral_constant<int, 2>{}); break;
+            case 3: if constexpr (WK > 2) tail(std::integral_constant<int, 3>{}); break;
+            case 4: if constexpr (WK > 4) tail(std::integral_constant<int, 4>{}); break;
+            case 5: if constexpr (WK > 4) tail(std::integral_constant<int, 5>{}); break;
+            case 6: if constexpr (WK > 4) tail(std::integral_constant<int, 6>{}); break;
+            case 7: if constexpr (WK > 4) tail(std::integral_constant<int, 7>{}); break;
+        }
+    }
 }
 
 // The tile configurations that are built: {MT, WN, WK, CP, DB}

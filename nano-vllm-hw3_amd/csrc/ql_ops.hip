@@ -78,9 +78,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const unsigned short* __r
         u16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float g = bf16_bits_to_f32(a[k]);
-            const float s = g / (1.f + __expf(-g));
-            o[k] = f32_to_bf16_bits(s * bf16_bits_to_f32(b[k]));
+            o[k] = silu_mul_bf16(bf16_bits_to_f32(a[k]), bf16_bits_to_f32(b[k]));
         }
         *(u16x8*)(out + t * I + c * 8) = o;
     }

@@ -80,6 +80,11 @@ class ModelRunner:
         budget = int(free - (1.0 - cfg.gpu_memory_utilization) * total) - (10 << 30)
         max_needed = cfg.max_num_seqs * ((cfg.max_model_len + self.block_size - 1) // self.block_size)
         cfg.num_kvcache_blocks = max(1, min(budget // block_bytes, max_needed))
+        if self.world_size > 1:
+            # every rank runs its own copy of the scheduler: they must agree on the block budget
+            n = torch.tensor([cfg.num_kvcache_blocks], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else self.device)
+            dist.all_reduce(n, op=dist.ReduceOp.MIN)
+            cfg.num_kvcache_blocks = int(n.item())
         assert cfg.num_kvcache_blocks > 0
         self.kv_cache = torch.empty(2, hf.num_hidden_layers, cfg.num_kvcache_blocks, self.block_size, num_kv_heads,
                                     hf.head_dim)

@@ -37,6 +37,12 @@ class _SideStreamAllReduce:
         if not y.is_cuda:
             dist.all_reduce(y)
             return y
+        if dist.get_backend() == "gloo":
+            # test transport (several ranks sharing one GPU): gloo moves host memory
+            h = y.cpu()
+            dist.all_reduce(h)
+            y.copy_(h)
+            return y
         main = torch.cuda.current_stream(y.device)
         side = self.side(y.device)
         side.wait_stream(main)

@@ -79,9 +79,15 @@ class ParallelLMHead(VocabParallelEmbedding):
     def forward(self, x):
         logits = F.linear(x, self.weight)
         if self.tp_size > 1:
-            parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
-            dist.all_gather(parts, logits)
-            logits = torch.cat(parts, -1)
+            if dist.get_backend() == "gloo" and logits.is_cuda:     # test transport: gloo moves host memory
+                host = logits.cpu()
+                parts = [torch.empty_like(host) for _ in range(self.tp_size)]
+                dist.all_gather(parts, host)
+                logits = torch.cat(parts, -1).to(logits.device)
+            else:
+                parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
+                dist.all_gather(parts, logits)
+                logits = torch.cat(parts, -1)
         return logits
 
 
@@ -134,7 +140,10 @@ class Qwen3MLP(nn.Module):
         self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False)
 
     def forward(self, x):
-        return self.down_proj(ops.silu_mul(self.gate_up_proj(x)))
+        h = self.gate_up_proj(x)
+        if not getattr(self.gate_up_proj, "silu_fused", False):   # else the GEMM epilogue already applied SiLU * mul
+            h = ops.silu_mul(h)
+        return self.down_proj(h)
 
 
 class Qwen3DecoderLayer(nn.Module):

@@ -84,9 +84,9 @@ def _flatten(x, n_out):
     return x.reshape(-1, x.shape[-1]), y_shape
 
 
-def _w8a16(x, qw, sw, bias, granularity, group_size, dtype):
+def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False):
     assert dtype in _DTYPES and qw.dtype == dtype
-    x2, y_shape = _flatten(x, qw.shape[0])
+    x2, y_shape = _flatten(x, qw.shape[0] // 2 if silu else qw.shape[0])
     Q.require_cuda(x2, torch.bfloat16, "x")
     Q.require_cuda(qw, dtype, "qw")
     sw32 = sw if sw.dtype == torch.float32 else sw.to(torch.float32)
@@ -97,6 +97,12 @@ def _w8a16(x, qw, sw, bias, granularity, group_size, dtype):
     N = qw.shape[0]
     assert qw.shape[1] == K, f"x has K={K} but qw has K={qw.shape[1]}"
     lib = Q.load()
+    if silu:
+        y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=x.device)
+        Q.check(lib.ql_gemm_w8a16_silu(Q.dtype_code(dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
+                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
+                                       group_size or 0, Q.stream_ptr(x.device)))
+        return y.view(y_shape)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     ws_ptr, ws_len = Q.workspace.get(x.device, lib.ql_gemm_workspace_bytes(M, N, K, granularity))
     Q.check(lib.ql_gemm_w8a16(Q.dtype_code(dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
@@ -106,27 +112,31 @@ def _w8a16(x, qw, sw, bias, granularity, group_size, dtype):
 
 
 @torch.no_grad()
-def per_tensor_matmul(x, qw, sw, bias, dtype):
+def per_tensor_matmul(x, qw, sw, bias, dtype, silu=False):
     """``(x.float() @ (qw.float() * sw).T).to(bf16) + bias`` fused (quantization.py:237-262)."""
-    return _w8a16(x, qw, sw, bias, Q.QL_PER_TENSOR, 0, dtype)
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_TENSOR, 0, dtype, silu)
 
 
 @torch.no_grad()
-def per_group_matmul(x, qw, sw, bias, group_size, dtype):
+def per_group_matmul(x, qw, sw, bias, group_size, dtype, silu=False):
     """Per-group dequant fused into the GEMM (quantization.py:265-307)."""
     assert qw.shape[1] % group_size == 0
-    return _w8a16(x, qw, sw, bias, Q.QL_PER_GROUP, group_size, dtype)
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_GROUP, group_size, dtype, silu)
 
 
 @torch.no_grad()
-def per_row_weight_only_matmul(x, qw, sw, bias, dtype):
+def per_row_weight_only_matmul(x, qw, sw, bias, dtype, silu=False):
     """W8A16 with per-output-channel scales: ``bf16((x @ q.T) * sw + bias)``; the numerics the
-    reference reaches through ``F.linear(x, fake_per_row_quant(W))`` (quantization.py:438-439)."""
-    return _w8a16(x, qw, sw, bias, Q.QL_PER_ROW, 0, dtype)
+    reference reaches through ``F.linear(x, fake_per_row_quant(W))`` (quantization.py:438-439).
+
+    ``silu=True`` (every matmul here): qw / sw / bias rows are in the interleaved gate/up strip order
+    of ``interleave_gate_up`` and the result is ``silu(gate) * up`` of shape [..., N/2], bit-identical
+    to the plain matmul on the un-interleaved weight followed by SiluAndMul."""
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_ROW, 0, dtype, silu)
 
 
 @torch.no_grad()
-def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None):
+def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False):
     """The dual-scale GEMM on already-quantized activations (quantization.py:54-144, 331-345)."""
     assert dtype in _DTYPES
     Q.require_cuda(qx, dtype, "qx")
@@ -139,6 +149,12 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None):
     N = qw.shape[0]
     assert qw.shape[1] == K
     lib = Q.load()
+    if silu:
+        y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=qx.device)
+        Q.check(lib.ql_gemm_w8a8_silu(Q.dtype_code(dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
+                                      Q.stream_ptr(qx.device)))
+        return y if y_shape is None else y.view(y_shape)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=qx.device)
     ws_ptr, ws_len = Q.workspace.get(qx.device, lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW))
     Q.check(lib.ql_gemm_w8a8(Q.dtype_code(dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
@@ -148,12 +164,23 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None):
 
 
 @torch.no_grad()
-def per_row_matmul(x, qw, sw, bias, dtype):
+def per_row_matmul(x, qw, sw, bias, dtype, silu=False):
     """Dynamic per-token activation quant + W8A8 GEMM (quantization.py:310-346)."""
-    x2, y_shape = _flatten(x, qw.size(0))
+    x2, y_shape = _flatten(x, qw.size(0) // 2 if silu else qw.size(0))
     assert x2.size(1) % 32 == 0, f"K({x2.size(1)}) must be multiple of 32"
     qx, sx = per_row_quant(x2.contiguous(), dtype)
-    return w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape)
+    return w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape, silu)
+
+
+def interleave_gate_up(t: torch.Tensor):
+    """Rows [gate (I) | up (I)] -> 32-row strips alternating gate, up: the weight arrangement of the
+    fused SiLU epilogue (row 64*s + j = gate row 32*s + j for j < 32, up row 32*s + j - 32 otherwise)."""
+    I = t.shape[0] // 2
+    assert t.shape[0] == 2 * I and I % 32 == 0, f"gate/up halves of {I} rows must be multiples of 32"
+    rest = tuple(t.shape[1:])
+    g = t[:I].reshape(I // 32, 1, 32, *rest)
+    u = t[I:].reshape(I // 32, 1, 32, *rest)
+    return torch.cat([g, u], dim=1).reshape(t.shape).contiguous()
 
 
 def reserve_workspace(max_tokens: int, shapes, device=None):
@@ -188,6 +215,21 @@ class _QBase(torch.nn.Module):
             return None
         return self.bias
 
+    silu_fused = False
+
+    def enable_silu_mul(self):
+        """Turn a merged gate/up projection into ``silu(gate) * up``: rearrange the rows once, then every
+        forward runs the GEMM with the fused epilogue and returns [..., N/2]."""
+        assert self.tp_dim != 1, "a row-parallel linear cannot carry the gate/up epilogue"
+        assert not self.silu_fused
+        self.qw = interleave_gate_up(self.qw)
+        if self.sw.dim() >= 1 and self.sw.shape[0] == self.qw.shape[0]:      # per-row [N] / per-group [N, K/g]
+            self.sw = interleave_gate_up(self.sw)
+        if self.bias is not None:
+            self.bias = interleave_gate_up(self.bias.data)
+        self.silu_fused = True
+        return self
+
     def _finish(self, y):
         if self.tp_dim == 1 and self.tp_size > 1:
             from nanovllm.layers.linear import tp_all_reduce
@@ -216,7 +258,7 @@ class QLinear(_QBase):
 
     def forward(self, x: torch.Tensor):
         fn = per_row_weight_only_matmul if self.weight_only else per_row_matmul
-        return self._finish(fn(x, self.qw, self.sw, self._bias_for_rank(), self.dtype))
+        return self._finish(fn(x, self.qw, self.sw, self._bias_for_rank(), self.dtype, self.silu_fused))
 
 
 class QTensorLinear(_QBase):
@@ -238,7 +280,8 @@ class QTensorLinear(_QBase):
         return m
 
     def forward(self, x: torch.Tensor):
-        return self._finish(per_tensor_matmul(x, self.qw, self._sw32, self._bias_for_rank(), self.dtype))
+        return self._finish(per_tensor_matmul(x, self.qw, self._sw32, self._bias_for_rank(), self.dtype,
+                                              self.silu_fused))
 
 
 class QGroupLinear(_QBase):
@@ -260,7 +303,8 @@ class QGroupLinear(_QBase):
         return m
 
     def forward(self, x: torch.Tensor):
-        return self._finish(per_group_matmul(x, self.qw, self.sw, self._bias_for_rank(), self.group_size, self.dtype))
+        return self._finish(per_group_matmul(x, self.qw, self.sw, self._bias_for_rank(), self.group_size, self.dtype,
+                                             self.silu_fused))
 
 
 # --------------------------------------------------------------------------- fake quant
@@ -319,28 +363,31 @@ def apply_weight_fake_quant(model, weight_fake_quant_fn=lambda x: x):
 apply_weight_quant = apply_weight_fake_quant   # quantization.py:499-513 is the same walk
 
 
-def _replace(model, make):
+def _replace(model, make, fuse_silu=True):
     for l in _layers(model):
         l.self_attn.qkv_proj = make(l.self_attn.qkv_proj)
         l.self_attn.o_proj = make(l.self_attn.o_proj)
         l.mlp.gate_up_proj = make(l.mlp.gate_up_proj)
+        if fuse_silu and (l.mlp.gate_up_proj.qw.shape[0] // 2) % 32 == 0:
+            l.mlp.gate_up_proj.enable_silu_mul()
         l.mlp.down_proj = make(l.mlp.down_proj)
     _empty_cache()
 
 
-def apply_per_row_quant(model, dtype, weight_only: bool = False):
-    """Replace the four linears per layer by QLinear (quantization.py:463-472)."""
-    _replace(model, lambda lin: QLinear.from_linear(lin, dtype, weight_only))
+def apply_per_row_quant(model, dtype, weight_only: bool = False, fuse_silu: bool = True):
+    """Replace the four linears per layer by QLinear (quantization.py:463-472).  ``fuse_silu`` (all
+    three rewriters) folds the MLP's SiLU * mul into the gate/up GEMM epilogue; results are bit-identical."""
+    _replace(model, lambda lin: QLinear.from_linear(lin, dtype, weight_only), fuse_silu)
 
 
-def apply_tensor_quant(model, dtype):
+def apply_tensor_quant(model, dtype, fuse_silu: bool = True):
     """quantization.py:475-484"""
-    _replace(model, lambda lin: QTensorLinear.from_linear(lin, dtype))
+    _replace(model, lambda lin: QTensorLinear.from_linear(lin, dtype), fuse_silu)
 
 
-def apply_group_quant(model, dtype, group_size: int):
+def apply_group_quant(model, dtype, group_size: int, fuse_silu: bool = True):
     """quantization.py:487-496"""
-    _replace(model, lambda lin: QGroupLinear.from_linear(lin, dtype, group_size))
+    _replace(model, lambda lin: QGroupLinear.from_linear(lin, dtype, group_size), fuse_silu)
 
 
 def apply_quant_torchao(model, linear_dtype=torch.float8_e4m3fn):

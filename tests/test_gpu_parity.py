@@ -216,6 +216,64 @@ def test_every_tile_configuration(NQ, tile, split):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+# ----------------------------------------------------------------------------- fused SiLU * mul epilogue
+@pytest.mark.parametrize("tile", [t for t in TILES if t[1] % 2 == 0])
+def test_fused_silu_epilogue_bit_identical(NQ, tile):
+    """gate/up GEMM with the SiLU*mul epilogue on the strip-interleaved weight == the plain GEMM on the
+    packed weight followed by the stand-alone SiLU*mul operator, bit for bit, for every arithmetic
+    variant and every tile that pairs column strips (M and N tails included)."""
+    from nanovllm import _qlinear as Q, ops
+    lib = Q.load()
+    M, I, K = 70, 160, 1152
+    rng = np.random.default_rng(5)
+    xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (2 * I, K), 0.05)
+    x, w = bf16_t(xb), bf16_t(wb)
+    bias = bf16_t(rand_bf16(rng, (2 * I,), 0.5))
+    il = NQ.interleave_gate_up
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], 1) == 0
+        for tdt in (torch.int8, torch.float8_e4m3fn):
+            for b in (None, bias):
+                bi = None if b is None else il(b)
+                qw, sw = NQ.per_row_quant(w, tdt)
+                for fn in (NQ.per_row_weight_only_matmul, NQ.per_row_matmul):
+                    ref = ops.silu_mul(fn(x, qw, sw, b, tdt))
+                    got = fn(x, il(qw), il(sw), bi, tdt, silu=True)
+                    assert got.shape == (M, I) and torch.equal(got, ref), (fn.__name__, tdt, tile)
+                qt, st = NQ.per_tensor_quant(w, tdt)
+                st = st.float().reshape(1)
+                assert torch.equal(NQ.per_tensor_matmul(x, il(qt), st, bi, tdt, silu=True),
+                                   ops.silu_mul(NQ.per_tensor_matmul(x, qt, st, b, tdt)))
+                if tile[0] <= 4:
+                    qg, sg = NQ.per_group_quant(w, 128, tdt)
+                    assert torch.equal(NQ.per_group_matmul(x, il(qg), il(sg), bi, 128, tdt, silu=True),
+                                       ops.silu_mul(NQ.per_group_matmul(x, qg, sg, b, 128, tdt)))
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 130, 256, 2048])
+def test_fused_silu_full_size_and_module(NQ, M):
+    """Qwen3-0.6B gate/up shape through the module API with the library's own tile choice: int8 W8A8 is
+    exact whatever the tile, so it must equal the unfused route bit for bit; the float variants are
+    compared at the GEMM tolerance (the two routes may pick different tiles, i.e. summation orders)."""
+    from nanovllm import ops
+    from nanovllm.layers.linear import MergedColumnParallelLinear
+    lin = MergedColumnParallelLinear(1024, [3072, 3072], bias=False).cuda()
+    g = torch.Generator(device="cuda").manual_seed(M)
+    lin.weight.data = (torch.randn(6144, 1024, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    x = torch.randn(M, 1024, device="cuda", dtype=torch.bfloat16, generator=g)
+    plain, fused = NQ.QLinear.from_linear(lin, torch.int8), NQ.QLinear.from_linear(lin, torch.int8).enable_silu_mul()
+    assert torch.equal(fused(x), ops.silu_mul(plain(x)))
+    for mk in (lambda: NQ.QLinear.from_linear(lin, torch.int8, weight_only=True),
+               lambda: NQ.QGroupLinear.from_linear(lin, torch.float8_e4m3fn, 128)):
+        a, b = ops.silu_mul(mk()(x)).float(), mk().enable_silu_mul()(x).float()
+        assert b.shape == (M, 3072)
+        assert ((a - b).abs() <= 2.0 ** -6 * a.abs() + 2e-3).all()
+    with pytest.raises(AssertionError):
+        NQ.interleave_gate_up(torch.zeros(2 * 48, 8))            # halves must be multiples of 32 rows
+
+
 @pytest.mark.parametrize("g", [32, 64, 128, 256, 512])
 def test_group_sizes(NQ, g):
     M, N, K = 40, 96, 1024

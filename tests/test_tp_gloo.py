@@ -39,7 +39,8 @@ def _install_oracle_doubles():
         q, s = O.per_row_quant(bits(x), "int8")
         return torch.from_numpy(q), torch.from_numpy(s)
 
-    def w8a16(x, qw, sw, bias, dtype):
+    def w8a16(x, qw, sw, bias, dtype, silu=False):
+        assert not silu
         x2 = x.reshape(-1, x.shape[-1])
         y = O.w8a16_rowscale_matmul(bits(x2), qw.numpy(), sw.numpy(), None if bias is None else bits(bias), "int8")
         return torch.from_numpy(y.view(np.int16)).view(torch.bfloat16).reshape(*x.shape[:-1], qw.shape[0])
