@@ -143,6 +143,15 @@ int ql_qknorm_rope_store(const void* qkv_bf16, const int64_t* positions, const f
                          void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int64_t T,
                          int Hq, int Hkv, int head_dim, void* stream);
 
+/* Prefill attention: causal self-attention over packed variable-length sequences, the
+ * flash_attn_varlen_func call of Attention.forward's prefill branch without a prefix cache
+ * (nanovllm/layers/attention.py:64-69).  q [T,Hq,128], k/v [T,Hkv,128], out [T,Hq,128] bf16;
+ * cu_seqlens int32 [num_seqs+1] in device memory, sequence s owns rows cu[s] .. cu[s+1]-1;
+ * max_seqlen >= the longest sequence (sizes the grid).  out = softmax(scale * q k^T + causal) v with
+ * f32 accumulation, probabilities rounded to bf16 before the second product.  Hq/Hkv in {1,2,4}. */
+int ql_attn_prefill(const void* q, const void* k, const void* v, const int* cu_seqlens, void* out,
+                    float scale, int num_seqs, int max_seqlen, int Hq, int Hkv, int head_dim, void* stream);
+
 /* Single-query attention over a paged KV cache: the decode half of Attention.forward
  * (nanovllm/layers/attention.py:59-75, flash_attn_with_kvcache there).  q/out [B,Hq,128];
  * caches [num_blocks, block_size, Hkv, 128]; block_tables [B, max_blocks]; context_lens [B]

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nanovllm", "_lib")
 LIB = os.path.join(OUT_DIR, "libqlinear.so")
-SOURCES = ["ql_quant.hip", "ql_gemm.hip", "ql_ops.hip", "ql_gemm_inst_bf16_i8_row.hip", "ql_gemm_inst_bf16_i8_group.hip",
+SOURCES = ["ql_quant.hip", "ql_gemm.hip", "ql_ops.hip", "ql_attn_prefill.hip", "ql_gemm_inst_bf16_i8_row.hip", "ql_gemm_inst_bf16_i8_group.hip",
            "ql_gemm_inst_bf16_fp8_row.hip", "ql_gemm_inst_bf16_fp8_group.hip", "ql_gemm_inst_i8_i8.hip",
            "ql_gemm_inst_fp8_fp8.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]

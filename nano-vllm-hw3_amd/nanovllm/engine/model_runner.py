@@ -113,7 +113,8 @@ class ModelRunner:
             slot = None
         else:
             slot = self._dev(slot_mapping, torch.int32)
-        set_context(AttnContext(is_prefill=True, cu_seqlens=cu, slot_mapping=slot))
+        set_context(AttnContext(is_prefill=True, cu_seqlens=cu, slot_mapping=slot,
+                                cu_seqlens_dev=self._dev(cu, torch.int32), max_seqlen=max(len(s) for s in seqs)))
         return self._dev(input_ids, torch.int64), self._dev(positions, torch.int64), cu
 
     def _init_decode_staging(self, max_bs, max_blocks):

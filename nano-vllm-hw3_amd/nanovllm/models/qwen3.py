@@ -1,7 +1,7 @@
 """Qwen3 decoder (the only model family of the reference, nanovllm/models/qwen3.py) as the host of
 the four quantized-linear call sites per layer.  Everything between the GEMMs runs as one fused HIP
-launch per operator (nanovllm/ops.py); attention is torch SDPA for prefill and a paged single-query
-kernel for decode."""
+launch per operator (nanovllm/ops.py); attention is a flash-style varlen kernel for prefill and a paged
+single-query kernel for decode."""
 from dataclasses import dataclass
 from typing import Optional
 
@@ -23,6 +23,8 @@ class AttnContext:
     slot_mapping: Optional[torch.Tensor] = None
     context_lens: Optional[torch.Tensor] = None
     block_tables: Optional[torch.Tensor] = None
+    cu_seqlens_dev: Optional[torch.Tensor] = None   # cu_seqlens as int32 on the device (built on demand)
+    max_seqlen: int = 0
 
 
 _CTX = AttnContext()
@@ -119,14 +121,11 @@ class Qwen3Attention(nn.Module):
                                         self.num_kv_heads, self.head_dim, self.k_cache, self.v_cache,
                                         ctx.slot_mapping, want_kv=ctx.is_prefill)
         if ctx.is_prefill:
-            o = torch.empty_like(q)
-            cu = ctx.cu_seqlens
-            for i in range(len(cu) - 1):
-                a, b = cu[i], cu[i + 1]
-                o[a:b] = F.scaled_dot_product_attention(
-                    q[a:b].transpose(0, 1).unsqueeze(0), k[a:b].transpose(0, 1).unsqueeze(0),
-                    v[a:b].transpose(0, 1).unsqueeze(0), is_causal=True, scale=self.scaling,
-                    enable_gqa=self.num_heads != self.num_kv_heads)[0].transpose(0, 1)
+            cu_dev = ctx.cu_seqlens_dev
+            if cu_dev is None:
+                cu_dev = torch.tensor(ctx.cu_seqlens, dtype=torch.int32, device=q.device)
+            max_len = ctx.max_seqlen or max(b - a for a, b in zip(ctx.cu_seqlens[:-1], ctx.cu_seqlens[1:]))
+            o = ops.attn_prefill(q, k, v, cu_dev, max_len, self.scaling)
         else:
             o = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scaling)
         return self.o_proj(o.view(o.shape[0], -1))

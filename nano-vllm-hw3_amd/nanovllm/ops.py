@@ -75,3 +75,20 @@ def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale):
                                      context_lens.data_ptr(), out.data_ptr(), scale, B, Hq, Hkv, D, block_size,
                                      max_blocks, ws_ptr, ws_len, Q.stream_ptr(q.device)))
     return out
+
+
+def attn_prefill(q, k, v, cu_seqlens, max_seqlen, scale):
+    """Causal self-attention over packed sequences: q [T,Hq,D], k/v [T,Hkv,D], cu_seqlens int32 [S+1] on
+    the device (sequence s owns rows cu[s]:cu[s+1]) -> out [T,Hq,D].  The varlen call of the reference's
+    prefill branch (nanovllm/layers/attention.py:64-69) without a prefix cache."""
+    Q.require_cuda(q, BF16, "q")
+    Q.require_cuda(k, BF16, "k")
+    Q.require_cuda(v, BF16, "v")
+    Q.require_cuda(cu_seqlens, torch.int32, "cu_seqlens")
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    assert k.shape == v.shape == (T, Hkv, D)
+    out = torch.empty_like(q)
+    Q.check(Q.load().ql_attn_prefill(q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(), out.data_ptr(),
+                                     scale, cu_seqlens.numel() - 1, int(max_seqlen), Hq, Hkv, D, Q.stream_ptr(q.device)))
+    return out
