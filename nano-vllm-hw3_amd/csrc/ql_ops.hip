@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const unsigned short* __r
 }
 
 // ---- per-head RMSNorm (optional) + rotate-half RoPE on q and k, and K/V scatter into the paged cache
-// One wave per (token, head); head_dim = 128: lane i holds elements i and i + 64, which are exactly
-// the (x1, x2) pair the rotation mixes.
+// Eight lanes per (token, head); head_dim = 128: lane s holds elements 8s .. 8s+7 and 64+8s .. 64+8s+7
+// (two 16-byte accesses), which are exactly the (x1, x2) pairs the rotation mixes, so only the
+// sum of squares of the norm crosses lanes (three shuffle steps inside the 8-lane group).
 __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
     const unsigned short* __restrict__ qkv, const int64_t* __restrict__ positions,
     const float* __restrict__ cos_sin, const unsigned short* __restrict__ qw,
@@ -94,50 +95,64 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
     unsigned short* __restrict__ k_out, unsigned short* __restrict__ v_out,
     unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
     const int* __restrict__ slot_mapping, int T, int Hq, int Hkv) {
-    const int lane = threadIdx.x & 63;
     const int heads = Hq + 2 * Hkv;
-    const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (widx >= (int64_t)T * heads) return;
-    const int t = (int)(widx / heads), h = (int)(widx % heads);
-    const unsigned short* src = qkv + ((size_t)t * heads + h) * 128;
-    float x1 = bf16_bits_to_f32(src[lane]), x2 = bf16_bits_to_f32(src[lane + 64]);
+    const int64_t pair = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;      // (token, head) index
+    const int s8 = (threadIdx.x & 7) * 8;
+    if (pair >= (int64_t)T * heads) return;
+    const int t = (int)(pair / heads), h = (int)(pair % heads);
+    const unsigned short* src = qkv + ((size_t)t * heads + h) * 128 + s8;
+    const u16x8 a1 = *(const u16x8*)src, a2 = *(const u16x8*)(src + 64);
     const int slot = slot_mapping ? slot_mapping[t] : -1;
     if (h >= Hq + Hkv) {   // V: copy only
-        const int hv = h - Hq - Hkv;
+        const size_t hv = h - Hq - Hkv;
         if (v_out) {
-            v_out[((size_t)t * Hkv + hv) * 128 + lane] = src[lane];
-            v_out[((size_t)t * Hkv + hv) * 128 + lane + 64] = src[lane + 64];
+            *(u16x8*)(v_out + ((size_t)t * Hkv + hv) * 128 + s8) = a1;
+            *(u16x8*)(v_out + ((size_t)t * Hkv + hv) * 128 + 64 + s8) = a2;
         }
         if (slot >= 0) {
-            v_cache[((size_t)slot * Hkv + hv) * 128 + lane] = src[lane];
-            v_cache[((size_t)slot * Hkv + hv) * 128 + lane + 64] = src[lane + 64];
+            *(u16x8*)(v_cache + ((size_t)slot * Hkv + hv) * 128 + s8) = a1;
+            *(u16x8*)(v_cache + ((size_t)slot * Hkv + hv) * 128 + 64 + s8) = a2;
         }
         return;
     }
+    float x1[8], x2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x1[j] = bf16_bits_to_f32(a1[j]); x2[j] = bf16_bits_to_f32(a2[j]); }
     const bool is_q = h < Hq;
     const unsigned short* nw = is_q ? qw : kw;
     if (nw) {
-        const float ss = wave_sum(x1 * x1 + x2 * x2);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x1[j] * x1[j] + x2[j] * x2[j];
+        ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
         const float inv = rsqrtf(ss * (1.f / 128.f) + eps);
-        x1 = round_to_bf16(round_to_bf16(x1 * inv) * bf16_bits_to_f32(nw[lane]));
-        x2 = round_to_bf16(round_to_bf16(x2 * inv) * bf16_bits_to_f32(nw[lane + 64]));
+        const u16x8 w1 = *(const u16x8*)(nw + s8), w2 = *(const u16x8*)(nw + 64 + s8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x1[j] = round_to_bf16(round_to_bf16(x1[j] * inv) * bf16_bits_to_f32(w1[j]));
+            x2[j] = round_to_bf16(round_to_bf16(x2[j] * inv) * bf16_bits_to_f32(w2[j]));
+        }
     }
-    const int64_t pos = positions[t];
-    const float c = cos_sin[pos * 128 + lane], s = cos_sin[pos * 128 + 64 + lane];
-    const unsigned short y1 = f32_to_bf16_bits(x1 * c - x2 * s);
-    const unsigned short y2 = f32_to_bf16_bits(x2 * c + x1 * s);
+    const float* cs = cos_sin + positions[t] * 128 + s8;
+    u16x8 y1, y2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float c = cs[j], sn = cs[64 + j];
+        y1[j] = f32_to_bf16_bits(x1[j] * c - x2[j] * sn);
+        y2[j] = f32_to_bf16_bits(x2[j] * c + x1[j] * sn);
+    }
     if (is_q) {
-        q_out[((size_t)t * Hq + h) * 128 + lane] = y1;
-        q_out[((size_t)t * Hq + h) * 128 + lane + 64] = y2;
+        *(u16x8*)(q_out + ((size_t)t * Hq + h) * 128 + s8) = y1;
+        *(u16x8*)(q_out + ((size_t)t * Hq + h) * 128 + 64 + s8) = y2;
     } else {
-        const int hk = h - Hq;
+        const size_t hk = h - Hq;
         if (k_out) {
-            k_out[((size_t)t * Hkv + hk) * 128 + lane] = y1;
-            k_out[((size_t)t * Hkv + hk) * 128 + lane + 64] = y2;
+            *(u16x8*)(k_out + ((size_t)t * Hkv + hk) * 128 + s8) = y1;
+            *(u16x8*)(k_out + ((size_t)t * Hkv + hk) * 128 + 64 + s8) = y2;
         }
         if (slot >= 0) {
-            k_cache[((size_t)slot * Hkv + hk) * 128 + lane] = y1;
-            k_cache[((size_t)slot * Hkv + hk) * 128 + lane + 64] = y2;
+            *(u16x8*)(k_cache + ((size_t)slot * Hkv + hk) * 128 + s8) = y1;
+            *(u16x8*)(k_cache + ((size_t)slot * Hkv + hk) * 128 + 64 + s8) = y2;
         }
     }
 }
@@ -150,7 +165,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
 // of K and of V per lane and token, 4 tokens per slot in flight.  Online softmax per token slot; the
 // 16 slot states of the workgroup are merged through LDS.  A sequence with more than one chunk
 // stores its per-chunk (max, sum, weighted V) state and a second, tiny launch merges the chunks in
-// order (an in-kernel merge behind agent-scope fences measured slower: one L2 write-back per chunk).
+// order.  (Merging in-kernel by the last chunk to arrive measured slower both ways: behind agent-scope
+// fences the L2 write-back / invalidate per chunk halves the stream rate, and with fence-free
+// write-through states the completion wait at the end of every workgroup still costs ~2 us per launch.)
 #ifndef QL_ATTN_CHUNK
 #define QL_ATTN_CHUNK 512
 #endif
@@ -197,8 +214,9 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
         for (int u = 0; u < U; ++u) {
             const int t = min(t0 + 16 * u, tend - 1);             // clamped: no divergent loads
             const size_t off = ((size_t)bt[t / block_size] * block_size + (t % block_size)) * Hkv * 128 + hoff;
-            kk[u] = *(const u16x8*)(k_cache + off);
-            vv[u] = *(const u16x8*)(v_cache + off);
+            // read-once stream: the non-temporal hint measured +5 % on the whole launch
+            kk[u] = __builtin_nontemporal_load((const u16x8*)(k_cache + off));
+            vv[u] = __builtin_nontemporal_load((const u16x8*)(v_cache + off));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -326,8 +344,8 @@ int ql_qknorm_rope_store(const void* qkv, const int64_t* positions, const float*
     }
     if (head_dim != 128) { set_error("ql_qknorm_rope_store: head_dim=%d (only 128 is built)", head_dim); return QL_ESHAPE; }
     if (T == 0) return QL_OK;
-    const int64_t waves = T * (Hq + 2 * Hkv);
-    const int64_t blocks = (waves + 3) / 4;
+    const int64_t pairs = T * (Hq + 2 * Hkv);                 // 8 lanes each, 32 per 256-thread block
+    const int64_t blocks = (pairs + 31) / 32;
     if (blocks > 0x7FFFFFFF) { set_error("ql_qknorm_rope_store: too many tokens"); return QL_ESHAPE; }
     hipLaunchKernelGGL(qknorm_rope_store_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        (const unsigned short*)qkv, positions, cos_sin, (const unsigned short*)q_norm_w,
