@@ -59,10 +59,10 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     const int64_t nblocks = (N + 32 * wn - 1) / (32 * wn);
     const int64_t kchunks = (K + kb - 1) / kb;
     const int64_t base = mblocks * nblocks;
-    // few tiles even at 32 x 32 (N = hidden size, small batch): split K so that each slice is one
-    // 1024-k chunk, combined in-kernel by the last arriver
+    // fewer tiles than CUs even at 32 x 32 (N = hidden size): split K so that each slice is one 1024-k
+    // chunk, combined in-kernel by the last arriver (measured: down_proj 11.1 -> 9.5 us at M = 64..128)
     int64_t split = 1;
-    if (base < 64) split = (K + 1023) / 1024;
+    if (base < 160) split = (K + 1023) / 1024;
     if (f_split > 0) split = f_split;
     if (silu) split = 1;                                    // gate and up meet in the epilogue of ONE workgroup
     if (split > 64) split = 64;

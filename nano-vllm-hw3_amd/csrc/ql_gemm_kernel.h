@@ -378,23 +378,22 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
             raw_t* slab = (raw_t*)p.partial + ((size_t)tile * S) * (WN * MT * 16 * 64) + (size_t)wn * (MT * 16 * 64) + lane;
             raw_t* mine = slab + (size_t)blockIdx.z * (WN * MT * 16 * 64);
+            // Partial tiles travel between workgroups (possibly on different XCDs, whose L2s are not
+            // coherent with each other) as agent-scope relaxed atomics: write-through stores, cache-
+            // bypassing loads.  Completed stores (vmcnt(0) + barrier) before the ticket and the ticket
+            // before the loads give the ordering without an L2 write-back / invalidate per workgroup.
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int rr = 0; rr < RN; ++rr) mine[(i * 16 + R0 + rr) * 64] = acc[i][R0 + rr];
+                for (int rr = 0; rr < RN; ++rr)
+                    __hip_atomic_store(mine + (i * 16 + R0 + rr) * 64, acc[i][R0 + rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                  // also: every wave is done with smem
             unsigned* flag = (unsigned*)smem;
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned t = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned last = (t == (unsigned)(S - 1)) ? 1u : 0u;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (last) __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *flag = last;
             }
             __syncthreads();
@@ -404,11 +403,12 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
 #pragma unroll
                 for (int rr = 0; rr < RN; ++rr) acc[i][R0 + rr] = 0;
             for (int s = 0; s < S; ++s) {
-                const raw_t* src = slab + (size_t)s * (WN * MT * 16 * 64);
+                raw_t* src = slab + (size_t)s * (WN * MT * 16 * 64);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < RN; ++rr) acc[i][R0 + rr] += src[(i * 16 + R0 + rr) * 64];
+                    for (int rr = 0; rr < RN; ++rr)
+                        acc[i][R0 + rr] += __hip_atomic_load(src + (i * 16 + R0 + rr) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 
