@@ -45,9 +45,36 @@ def workload():
     return prompts, max_tokens
 
 
-def gemm_bytes(M, N, K):
-    """Algorithmic bytes of one W8A16 linear call: 1-byte weights + f32 row scales + bf16 x in + bf16 y out."""
-    return N * K + 4 * N + 2 * M * K + 2 * M * N
+def gemm_bytes(M, N, K, n_out=None):
+    """Algorithmic bytes of one W8A16 linear call: 1-byte weights + f32 row scales + bf16 x in + bf16 y out
+    (n_out = N/2 columns leave the gate/up GEMM whose epilogue applies SiLU * mul)."""
+    return N * K + 4 * N + 2 * M * K + 2 * M * (N if n_out is None else n_out)
+
+
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r01_decode_gemm_traffic.json")
+
+
+def pmc_traffic(mods4, buckets):
+    """HBM-side bytes per launch, weighted over the same (batch bucket, layer shape) mix as `achieved`, from
+    the committed rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950 requires, + WRITE_SIZE; see
+    tools/pmc_traffic.py).  Counters cannot be read from inside this process, hence the table; null when
+    the table is missing or the model is not the one it was measured on."""
+    if not os.path.exists(TRAFFIC_TABLE):
+        return None
+    table = json.load(open(TRAFFIC_TABLE))["traffic_bytes"]
+    names = ["qkv", "o", "gate_up_silu", "down"]
+    want = {"qkv": (4096, 1024), "o": (1024, 2048), "gate_up_silu": (6144, 1024), "down": (1024, 3072)}
+    for nm, m in zip(names, mods4):
+        if tuple(m.qw.shape) != want[nm] or (nm == "gate_up_silu") != bool(getattr(m, "silu_fused", False)):
+            return None
+    tot = n = 0
+    for M, cnt in buckets.items():
+        for nm in names:
+            keys = sorted(int(k) for k in table[nm])
+            k = min(keys, key=lambda v: (abs(v - M), v))
+            tot += table[nm][str(k)] * cnt
+            n += cnt
+    return int(tot / n) if n else None
 
 
 def measure_decode_gemm(llm, step_batches):
@@ -84,7 +111,9 @@ def measure_decode_gemm(llm, step_batches):
                     for m4 in mods:
                         for x, m in zip(xs, m4):
                             m(x)
-                nbytes = sum(gemm_bytes(M, m.qw.shape[0], m.qw.shape[1]) for m4 in mods for m in m4)
+                nbytes = sum(gemm_bytes(M, m.qw.shape[0], m.qw.shape[1],
+                                        m.qw.shape[0] // 2 if getattr(m, "silu_fused", False) else None)
+                             for m4 in mods for m in m4)
                 nlaunch = sum(len(m4) for m4 in mods)
                 g.replay()
                 side.synchronize()
@@ -106,10 +135,38 @@ def measure_decode_gemm(llm, step_batches):
     avg_us = tot_t / tot_n * 1e6
     achieved = tot_b / tot_t / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(mods[0], buckets),
             "kernel": "ql::qgemm_kernel (decode W8A16 GEMM, all four layer shapes, M = graph bucket)",
             "avg_launch_us": round(avg_us, 2), "avg_algorithmic_bytes": int(tot_b / tot_n),
             "launches_weighted": int(tot_n)}
+
+
+def measure_prefill_gemm(llm, M=16384):
+    """MFMA-bound side of the same kernel: the four layer GEMMs at a prefill-sized batch (M = the scheduler's
+    max_num_batched_tokens), HIP events around 5 back-to-back rounds; achieved = 2*M*N*K flop / time against
+    the dense bf16 MFMA peak (the W8A16 kernel contracts on bf16 MFMA after widening the weights)."""
+    from nanovllm.utils.quantization import QLinear
+    l0 = llm.model_runner.model.model.layers[0]
+    mods = [l0.self_attn.qkv_proj, l0.self_attn.o_proj, l0.mlp.gate_up_proj, l0.mlp.down_proj]
+    if not isinstance(mods[0], QLinear):
+        return None
+    with torch.inference_mode():
+        xs = [torch.randn(M, m.qw.shape[1], device="cuda", dtype=torch.bfloat16) for m in mods]
+        for x, m in zip(xs, mods):
+            m(x)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            for x, m in zip(xs, mods):
+                m(x)
+        e.record()
+        torch.cuda.synchronize()
+    t = s.elapsed_time(e) * 1e-3 / 5
+    flop = sum(2.0 * M * m.qw.shape[0] * m.qw.shape[1] for m in mods)
+    tf = flop / t / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "traffic": None, "kernel": f"ql::qgemm_kernel (prefill W8A16 GEMM, four layer shapes, M = {M})"}
 
 
 def cpu_baseline():
@@ -206,9 +263,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    roof = None
+    roof = roof_prefill = None
     if rank == 0 and not args.no_roofline and args.quant != "bf16":
         roof = measure_decode_gemm(llm, step_batches[: len(step_batches) // max(args.steps, 1)])
+        roof_prefill = measure_prefill_gemm(llm) if world == 1 else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -223,7 +281,7 @@ def main():
                                    "(133,966 output tokens), Qwen3-0.6B random-init, "
                                    f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, hipGraph decode",
                        "parallelism": f"tp{world}", "decode_steps": len(step_batches) // max(args.steps, 1)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

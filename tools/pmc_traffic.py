@@ -1,0 +1,66 @@
+"""PMC target: launches the decode W8A16 GEMM at every (Qwen3-0.6B layer shape, batch bucket) REPS times in
+a fixed order, so that a rocprofv3 --pmc pass over it can be mapped back to (shape, M) by dispatch order.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_traffic.py
+    rocprofv3 --pmc WRITE_SIZE ...                                    (separate pass)
+    python3 tools/pmc_traffic.py --parse <fetch_dir> <write_dir> > profiles/<name>.json
+"""
+import csv, glob, json, os, statistics, sys
+
+SHAPES = [("qkv", 4096, 1024), ("o", 1024, 2048), ("gate_up_silu", 6144, 1024), ("down", 1024, 3072)]
+MS = [1, 8, 16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 208, 224, 240, 256]
+REPS = 5
+
+
+def run():
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "nano-vllm-hw3_amd"))
+    from nanovllm.utils import quantization as NQ
+    torch.manual_seed(0)
+    for name, N, K in SHAPES:
+        ws = []
+        for _ in range(REPS):
+            w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+            q, s = NQ.per_row_quant(w, torch.int8)
+            if name.endswith("silu"):
+                q, s = NQ.interleave_gate_up(q), NQ.interleave_gate_up(s)
+            ws.append((q, s))
+        for M in MS:
+            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            for q, s in ws:
+                NQ.per_row_weight_only_matmul(x, q, s, None, torch.int8, silu=name.endswith("silu"))
+                torch.cuda.synchronize()          # one dispatch at a time: the counter pass drops records otherwise
+
+
+def read(d, counter):
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    rows = [r for r in csv.DictReader(open(f)) if "qgemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    vals = [float(r["Counter_Value"]) for r in rows]
+    assert len(vals) == len(SHAPES) * len(MS) * REPS, (len(vals), counter)
+    return vals
+
+
+def parse(fetch_dir, write_dir):
+    fetch, write = read(fetch_dir, "FETCH_SIZE"), read(write_dir, "WRITE_SIZE")
+    out = {"note": "HBM-side bytes per launch of the decode W8A16 GEMM from rocprofv3 PMC passes (tools/pmc_traffic.py): "
+                   "traffic = 2 * FETCH_SIZE (gfx950 reports half the bytes of 16-B-per-lane streaming reads) + WRITE_SIZE, "
+                   "both in KiB units; median of 5 launches on distinct weight copies",
+           "traffic_bytes": {}}
+    i = 0
+    for name, N, K in SHAPES:
+        out["traffic_bytes"][name] = {}
+        for M in MS:
+            f = statistics.median(fetch[i:i + REPS]) * 1024 * 2
+            w = statistics.median(write[i:i + REPS]) * 1024
+            out["traffic_bytes"][name][str(M)] = int(f + w)
+            i += REPS
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--parse":
+        parse(sys.argv[2], sys.argv[3])
+    else:
+        run()
