@@ -28,9 +28,10 @@ def load_hf_config(model_dir: str) -> SimpleNamespace:
 
 @dataclass
 class Config:
-    """The reference's Config (nanovllm/config.py:9-35) plus ``load_format`` ("auto" reads
-    *.safetensors; "dummy" random-initialises the weights on the GPU - used by the benchmark, which
-    has no checkpoint to read)."""
+    """The reference's Config (nanovllm/config.py:9-35) plus ``load_format``: "auto" reads *.safetensors
+    and quantizes as configured; "dummy" random-initialises the weights on the GPU (the benchmark has no
+    checkpoint to read); "quantized" reads a pre-quantized checkpoint written by
+    nanovllm.utils.checkpoint.save_quantized (its quant_config.json overrides quant_type / linear_dtype)."""
     model: str
     max_num_batched_tokens: int = 16384
     max_num_seqs: int = 512

@@ -25,13 +25,20 @@ class ModelRunner:
         torch.set_default_device(self.device)
         try:
             self.model = Qwen3ForCausalLM(hf)
-            if config.load_format == "dummy":
-                init_dummy_weights(self.model, hf, seed=0)
+            if config.load_format == "quantized":
+                # a pre-quantized checkpoint: no bf16 read, no re-quantization
+                from nanovllm.utils.checkpoint import load_quantized
+                qc = load_quantized(self.model, config.model)
+                config.quant_type, config.group_size = qc["quant_type"], qc["group_size"] or config.group_size
+                config.linear_dtype = getattr(torch, qc["linear_dtype"])
             else:
-                load_model(self.model, config.model)
-            # quantization happens after loading, before warm-up and graph capture (reference:
-            # nanovllm/engine/model_runner.py:36-57)
-            apply_quant_from_config(self.model, config)
+                if config.load_format == "dummy":
+                    init_dummy_weights(self.model, hf, seed=0)
+                else:
+                    load_model(self.model, config.model)
+                # quantization happens after loading, before warm-up and graph capture (reference:
+                # nanovllm/engine/model_runner.py:36-57)
+                apply_quant_from_config(self.model, config)
             self._reserve_gemm_workspace()
             self.allocate_kv_cache()
             self.graphs = {}

@@ -256,6 +256,17 @@ class QLinear(_QBase):
         m._init_tp(*_tp_info(other))
         return m
 
+    @classmethod
+    def from_quantized(cls, other, dtype, qw, sw, bias=None, weight_only: bool = False):
+        """Build from stored tensors (a pre-quantized checkpoint) instead of quantizing ``other.weight``;
+        ``other`` only supplies the tensor-parallel role of the linear being replaced."""
+        assert dtype in _DTYPES and qw.dtype == dtype and sw.dtype == torch.float32 and sw.shape == (qw.shape[0],)
+        m = cls.__new__(cls)
+        torch.nn.Module.__init__(m)
+        m.dtype, m.weight_only, m.qw, m.sw, m.bias = dtype, weight_only, qw, sw, bias
+        m._init_tp(*_tp_info(other))
+        return m
+
     def forward(self, x: torch.Tensor):
         fn = per_row_weight_only_matmul if self.weight_only else per_row_matmul
         return self._finish(fn(x, self.qw, self.sw, self._bias_for_rank(), self.dtype, self.silu_fused))
@@ -279,6 +290,17 @@ class QTensorLinear(_QBase):
         m._init_tp(*_tp_info(other))
         return m
 
+    @classmethod
+    def from_quantized(cls, other, dtype, qw, sw, bias=None):
+        assert dtype in _DTYPES and qw.dtype == dtype and sw.numel() == 1
+        m = cls.__new__(cls)
+        torch.nn.Module.__init__(m)
+        m.dtype, m.qw, m.bias = dtype, qw, bias
+        m.sw = sw.reshape(()).to(torch.bfloat16)
+        m._sw32 = m.sw.to(torch.float32).reshape(1)
+        m._init_tp(*_tp_info(other))
+        return m
+
     def forward(self, x: torch.Tensor):
         return self._finish(per_tensor_matmul(x, self.qw, self._sw32, self._bias_for_rank(), self.dtype,
                                               self.silu_fused))
@@ -299,6 +321,16 @@ class QGroupLinear(_QBase):
     @classmethod
     def from_linear(cls, other, dtype, group_size: int):
         m = cls(dtype, other.weight.data, other.bias, group_size)
+        m._init_tp(*_tp_info(other))
+        return m
+
+    @classmethod
+    def from_quantized(cls, other, dtype, qw, sw, bias, group_size: int):
+        assert dtype in _DTYPES and qw.dtype == dtype and sw.dtype == torch.float32
+        assert qw.shape[1] % group_size == 0 and sw.shape == (qw.shape[0], qw.shape[1] // group_size)
+        m = cls.__new__(cls)
+        torch.nn.Module.__init__(m)
+        m.dtype, m.group_size, m.qw, m.sw, m.bias = dtype, group_size, qw, sw, bias
         m._init_tp(*_tp_info(other))
         return m
 

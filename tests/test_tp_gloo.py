@@ -154,3 +154,77 @@ def test_weight_loader_sharding_matches_reference(world):
 
 def test_tp2_forward_bf16_and_quantized():
     _spawn(_worker_forward, 2)
+
+
+def _worker_checkpoint_shards(rank, world, port):
+    """Shards of a pre-quantized checkpoint: cut by the modules' own weight loaders, they must equal
+    explicit slices of the unsharded tensors, and the sharded W8A16 forward (oracle test double) must
+    reproduce the unsharded one exactly for column-parallel and up to the bf16 all-reduce for row-parallel."""
+    _setup(rank, world, port)
+    try:
+        from oracle import qlinear_oracle as O
+        from nanovllm.layers import linear as L
+        from nanovllm.utils import checkpoint as C, quantization as NQ
+        _install_oracle_doubles()
+        g = torch.Generator().manual_seed(3)
+        hidden, head, nh, nkv, inter, G = 256, 8, 8, 4, 128, 32
+
+        def rq(n, k):
+            return torch.randint(-127, 128, (n, k), dtype=torch.int8, generator=g)
+
+        def rs(*shape):
+            return torch.rand(*shape, generator=g) * 1e-2 + 1e-3
+        qkv = L.QKVParallelLinear(hidden, head, nh, nkv)
+        gu = L.MergedColumnParallelLinear(hidden, [inter, inter])
+        dn = L.RowParallelLinear(inter, hidden)
+        # --- per row
+        Nq, Nk = nh * head, nkv * head
+        q_full, s_full = rq(Nq + 2 * Nk, hidden), rs(Nq + 2 * Nk)
+        q, s, _ = C.shard_quantized(qkv, q_full, s_full, None, "per_row")
+        rows = torch.cat([torch.arange(Nq // world) + rank * Nq // world,
+                          Nq + torch.arange(Nk // world) + rank * Nk // world,
+                          Nq + Nk + torch.arange(Nk // world) + rank * Nk // world])
+        assert torch.equal(q, q_full[rows]) and torch.equal(s, s_full[rows])
+        q_full, s_full = rq(2 * inter, hidden), rs(2 * inter)
+        q, s, _ = C.shard_quantized(gu, q_full, s_full, None, "per_row")
+        rows = torch.cat([torch.arange(inter // world) + rank * inter // world,
+                          inter + torch.arange(inter // world) + rank * inter // world])
+        assert torch.equal(q, q_full[rows]) and torch.equal(s, s_full[rows])
+        q_full, s_full, b_full = rq(hidden, inter), rs(hidden), torch.randn(hidden, generator=g).to(torch.bfloat16)
+        q, s, b = C.shard_quantized(dn, q_full, s_full, b_full, "per_row")
+        k = inter // world
+        assert torch.equal(q, q_full[:, rank * k:(rank + 1) * k]) and torch.equal(s, s_full) and torch.equal(b, b_full)
+        # the sharded row-parallel module multiplies the SAME quantized weights as the unsharded one
+        x = (torch.randn(5, inter, generator=g) * 0.5).to(torch.bfloat16)
+        mod = NQ.QLinear.from_quantized(dn, torch.int8, q, s, b, weight_only=True)
+        y = mod(x[:, rank * k:(rank + 1) * k].contiguous())
+        ref = NQ.per_row_weight_only_matmul(x, q_full, s_full, b_full, torch.int8)
+        # (each rank's partial is rounded to bf16 and the all-reduce adds in bf16)
+        assert ((y.float() - ref.float()).abs() <= 2.0 ** -6 * ref.float().abs() + 4e-2).all()
+        # --- per group: a row-parallel shard takes its K/g columns of the scales
+        sg_full = rs(hidden, inter // G)
+        q, s, _ = C.shard_quantized(dn, q_full, sg_full, None, "per_group")
+        assert torch.equal(s, sg_full[:, rank * k // G:(rank + 1) * k // G]) and q.shape == (hidden, k)
+        sg_full = rs(2 * inter, hidden // G)
+        q, s, _ = C.shard_quantized(gu, rq(2 * inter, hidden), sg_full, None, "per_group")
+        assert torch.equal(s, sg_full[rows])
+        # --- per tensor: the scalar travels unchanged
+        q, s, _ = C.shard_quantized(dn, q_full, torch.tensor([0.01]), None, "per_tensor")
+        assert s.numel() == 1 and q.shape == (hidden, k)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_quantized_checkpoint_sharding(world):
+    _spawn(_worker_checkpoint_shards, world)
+
+
+def test_gate_up_interleave_round_trip():
+    from nanovllm.utils import checkpoint as C, quantization as NQ
+    t = torch.arange(2 * 96 * 3).reshape(2 * 96, 3)
+    il = NQ.interleave_gate_up(t)
+    assert torch.equal(il[:32], t[:32]) and torch.equal(il[32:64], t[96:128]) and torch.equal(il[64:96], t[32:64])
+    assert torch.equal(C.deinterleave_gate_up(il), t)
+    v = torch.arange(2 * 64)
+    assert torch.equal(C.deinterleave_gate_up(NQ.interleave_gate_up(v)), v)
