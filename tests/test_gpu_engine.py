@@ -407,3 +407,25 @@ def test_quantized_checkpoint_round_trip(tiny_dir, tmp_path, quant):
     ta = [o["token_ids"] for o in a.generate(_prompts(), sp)]
     tb = [o["token_ids"] for o in b.generate(_prompts(), sp)]
     assert ta == tb
+
+
+def test_perplexity_harness_quantized_vs_bf16(tiny_dir):
+    """The PPL loop on the tiny random model: quantized configurations must land next to bf16 (weights
+    ~N(0, 0.02) make the logits small, so the NLL is ~ln(vocab) and quantization may move it only slightly),
+    and the W8A16 per-row configuration closest of all."""
+    import math
+    from nanovllm import LLM
+    from nanovllm.utils.ppl import total_nll
+    g = torch.Generator().manual_seed(7)
+    seqs = [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (300, 70, 2, 1)]
+    res = {}
+    for name, kw in (("bf16", {}), ("w8a16", dict(quant_type="per_row_weight_only", linear_dtype=torch.int8)),
+                     ("w8a8_fp8", dict(quant_type="per_row", linear_dtype=torch.float8_e4m3fn)),
+                     ("g128", dict(quant_type="per_group", linear_dtype=torch.int8, group_size=128))):
+        llm = LLM(tiny_dir, load_format="dummy", enforce_eager=True, max_model_len=512, max_num_seqs=16, **kw)
+        loss, count = total_nll(llm.model_runner.model, seqs, max_length=128)
+        assert count == 299 + 69 + 1
+        res[name] = loss / count
+    assert abs(res["bf16"] - math.log(1024)) < 0.5
+    for name in ("w8a16", "w8a8_fp8", "g128"):
+        assert abs(res[name] - res["bf16"]) < 0.02, res
