@@ -41,6 +41,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
         const int64_t blocks = ((M + 32 * t.mt - 1) / (32 * t.mt)) * ((N + 32 * t.wn - 1) / (32 * t.wn));
         if (blocks >= 160) pick = i;
     }
+    // at most 32 rows: a taller tile would only re-read the clamped last row, and the 32-column tile keeps
+    // the most weight bytes in flight per CU (measured on the 0.6B and 4B layer shapes)
+    if (M <= 32 && !silu) pick = 0;
     int mt = ladder[pick].mt, wn = ladder[pick].wn, wk = ladder[pick].wk, cp = ladder[pick].cp;
     // prefill-sized problems: thousands of 64 x 128 tiles; four waves each running the whole K with
     // the double-buffered pipeline measured best (the taller tiles lose occupancy to registers)
@@ -63,6 +66,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     // chunk, combined in-kernel by the last arriver (measured: down_proj 11.1 -> 9.5 us at M = 64..128)
     int64_t split = 1;
     if (base < 160) split = (K + 1023) / 1024;
+    else if (base < 512 && K >= 4096) split = (K + 4095) / 4096;   // long K: at most four chunks per slice
     if (f_split > 0) split = f_split;
     if (silu) split = 1;                                    // gate and up meet in the epilogue of ONE workgroup
     if (split > 64) split = 64;
