@@ -89,6 +89,13 @@ __device__ __forceinline__ bf16x8 widen8(int d0, int d1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// 16-byte load through an explicitly GLOBAL pointer: pointers that arrive inside the by-value parameter struct
+// are generic to the compiler, and a generic (flat) load also counts against lgkmcnt, so every LDS wait in the
+// main loop would wait for the weight stream as well
+__device__ __forceinline__ i32x4 gload16(const void* ptr) {
+    return *(const __attribute__((address_space(1))) i32x4*)ptr;
+}
+
 template <int RB>
 __device__ __forceinline__ int lds_off(int row, int ci) {
     constexpr int CPR = RB / 16;                       // 16-byte pieces per row
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
     auto load_w1 = [&](auto chk, int kc, int c) -> i32x4 {
         const int kb = kc + wk * C::KW + c * 32;
-        if (!decltype(chk)::value || kb < kend) return *(const i32x4*)(p.w + kb + woff);
+        if (!decltype(chk)::value || kb < kend) return gload16(p.w + kb + woff);
         return i32x4{0, 0, 0, 0};
     };
     auto load_x = [&](auto chk, int kc) {
@@ -200,14 +207,14 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             const unsigned char* xs = p.x + (size_t)kc * C::AB;
 #pragma unroll
             for (int j = 0; j < C::NP; ++j)
-                sreg[j] = *(const i32x4*)(xs + (size_t)j * RS * p.K * C::AB + off);
+                sreg[j] = gload16(xs + (size_t)j * RS * p.K * C::AB + off);
         } else {
             // last row block: rows past M re-read row M-1 (their outputs are never stored)
 #pragma unroll
             for (int j = 0; j < C::NP; ++j) {
                 const int gm = min(m0 + st_row0 + j * RS, p.M - 1);
                 const int k = (kc + st_k < kend) ? kc + st_k : k0;
-                sreg[j] = *(const i32x4*)(p.x + ((size_t)gm * p.K + k) * C::AB);
+                sreg[j] = gload16(p.x + ((size_t)gm * p.K + k) * C::AB);
             }
         }
     };
@@ -232,17 +239,17 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         const int kb = kc + wk * C::KW + c * 32;   // first k of this step (wave-uniform)
         if (decltype(chk)::value && kb >= kend) return;
         const int base_c = (wk * CP + c) * APS;    // first piece of the step in an LDS row (uniform)
-        // piece index (base_c | lane part) with the low bits XOR-swizzled by the row
-        const unsigned char* a0 = smem + buf * C::XBYTES + a_row + ((base_c & ~SWZ_MASK) << 4) +
-                                  (((base_c & SWZ_MASK) << 4) ^ a_g4);
+        // piece index (base_c | lane part) with the low bits XOR-swizzled by the row; kept as an LDS byte OFFSET
+        // (an integer), not a pointer: xor-ing a pointer through uintptr_t makes it generic and the read a flat load
+        const int a0 = buf * C::XBYTES + a_row + ((base_c & ~SWZ_MASK) << 4) + (((base_c & SWZ_MASK) << 4) ^ a_g4);
         if constexpr (ACT == ACT_BF16) {
             const bf16x8 blo = widen8<FP8W>(w[0], w[1]);
             const bf16x8 bhi = widen8<FP8W>(w[2], w[3]);
-            const unsigned char* a1 = (const unsigned char*)((uintptr_t)a0 ^ 16);   // piece index + 1 == ^1 (index is even)
+            const int a1 = a0 ^ 16;                                // piece index + 1 == ^1 (index is even)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const bf16x8 alo = *(const bf16x8*)(a0 + i * 32 * RB);
-                const bf16x8 ahi = *(const bf16x8*)(a1 + i * 32 * RB);
+                const bf16x8 alo = *(const bf16x8*)(smem + a0 + i * 32 * RB);
+                const bf16x8 ahi = *(const bf16x8*)(smem + a1 + i * 32 * RB);
                 if (GROUP) {
                     accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, accg[i], 0, 0, 0);
                     accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, accg[i], 0, 0, 0);
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const i32x4 a = *(const i32x4*)(a0 + i * 32 * RB);
+                const i32x4 a = *(const i32x4*)(smem + a0 + i * 32 * RB);
                 if constexpr (ACT == ACT_I8) {
                     acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, acc[i], 0, 0, 0);
                 } else {
