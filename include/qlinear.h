@@ -143,6 +143,10 @@ int ql_qknorm_rope_store(const void* qkv_bf16, const int64_t* positions, const f
                          void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int64_t T,
                          int Hq, int Hkv, int head_dim, void* stream);
 
+/* Greedy sampler (nanovllm/layers/sampler.py:10-12): out[t] = argmax_v logits[t, v] over bf16 logits [T, V],
+ * the smallest index among equal maxima.  V % 8 == 0. */
+int ql_argmax_rows(const void* logits_bf16, int64_t* out, int64_t T, int64_t V, void* stream);
+
 /* Prefill attention: causal self-attention over packed variable-length sequences, the
  * flash_attn_varlen_func call of Attention.forward's prefill branch without a prefix cache
  * (nanovllm/layers/attention.py:64-69).  q [T,Hq,128], k/v [T,Hkv,128], out [T,Hq,128] bf16;

@@ -296,6 +296,44 @@ __global__ __launch_bounds__(256) void paged_attn_combine_kernel(const int* __re
     }
 }
 
+// ---- greedy sampling: index of the row maximum of bf16 logits (smallest index among equal maxima) ---------
+// One workgroup per row, 16-byte loads; the reference's sampler takes the argmax of the logits
+// (nanovllm/layers/sampler.py:10-12).  NaNs never win.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short* __restrict__ x,
+                                                           int64_t* __restrict__ out, int64_t V) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const unsigned short* row = x + (size_t)blockIdx.x * V;
+    float best = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    const int64_t nvec = V >> 3;
+    for (int64_t c = threadIdx.x; c < nvec; c += 1024) {
+        const u16x8 a = __builtin_nontemporal_load((const u16x8*)(row + c * 8));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = bf16_bits_to_f32(a[k]);
+            if (v > best) { best = v; bi = (int)(c * 8 + k); }     // ascending index within a thread: first maximum wins
+        }
+    }
+    for (int64_t i = (nvec << 3) + threadIdx.x; i < V; i += 1024) {
+        const float v = bf16_bits_to_f32(row[i]);
+        if (v > best) { best = v; bi = (int)i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        out[blockIdx.x] = (bi == 0x7FFFFFFF) ? 0 : bi;
+    }
+}
+
 }  // namespace ql
 
 using namespace ql;
@@ -353,6 +391,17 @@ int ql_qknorm_rope_store(const void* qkv, const int64_t* positions, const float*
                        (unsigned short*)v_out, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, (int)T,
                        Hq, Hkv);
     QL_CHECK_LAUNCH("ql_qknorm_rope_store");
+    return QL_OK;
+}
+
+int ql_argmax_rows(const void* logits, int64_t* out, int64_t T, int64_t V, void* stream) {
+    if (T < 0 || V <= 0 || (T > 0 && (!logits || !out))) { set_error("ql_argmax_rows: bad argument"); return QL_EINVAL; }
+    if (V > 0x7FFFFFFF || T > 0x7FFFFFFF) { set_error("ql_argmax_rows: shape too large"); return QL_ESHAPE; }
+    if (V % 8) { set_error("ql_argmax_rows: V=%lld must be a multiple of 8", (long long)V); return QL_ESHAPE; }
+    if (T == 0) return QL_OK;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)T), dim3(1024), 0, as_stream(stream), (const unsigned short*)logits,
+                       out, V);
+    QL_CHECK_LAUNCH("ql_argmax_rows");
     return QL_OK;
 }
 

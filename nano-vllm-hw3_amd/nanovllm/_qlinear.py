@@ -37,6 +37,7 @@ SIGNATURES = {
     "ql_silu_mul": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_qknorm_rope_store": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),
+    "ql_argmax_rows": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_attn_prefill": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                                  _c_int, _c_vp]),
     "ql_paged_attn_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),

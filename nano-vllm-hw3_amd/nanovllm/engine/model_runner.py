@@ -208,7 +208,12 @@ class ModelRunner:
                 gv = self.graph_vars
                 self.graphs[gbs].replay()
                 logits = gv["logits"][:bs]
-        token_ids = logits.argmax(dim=-1).tolist()     # greedy sampler (layers/sampler.py:10-12)
+        # greedy sampler (layers/sampler.py:10-12)
+        if logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0 and logits.is_contiguous():
+            from nanovllm import ops
+            token_ids = ops.argmax_rows(logits).tolist()
+        else:
+            token_ids = logits.argmax(dim=-1).tolist()
         return token_ids
 
     @torch.inference_mode()

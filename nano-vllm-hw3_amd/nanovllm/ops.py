@@ -92,3 +92,12 @@ def attn_prefill(q, k, v, cu_seqlens, max_seqlen, scale):
     Q.check(Q.load().ql_attn_prefill(q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens.data_ptr(), out.data_ptr(),
                                      scale, cu_seqlens.numel() - 1, int(max_seqlen), Hq, Hkv, D, Q.stream_ptr(q.device)))
     return out
+
+
+def argmax_rows(logits):
+    """Greedy sampling: int64 [T] = argmax over the last dim of bf16 logits [T, V] (first index among ties)."""
+    Q.require_cuda(logits, BF16, "logits")
+    T, V = logits.shape
+    out = torch.empty((T,), dtype=torch.int64, device=logits.device)
+    Q.check(Q.load().ql_argmax_rows(logits.data_ptr(), out.data_ptr(), T, V, Q.stream_ptr(logits.device)))
+    return out

@@ -61,6 +61,20 @@ def test_silu_mul_matches_torch():
         _close(ops.silu_mul(x), ref, rtol=2 ** -7, atol=1e-5)
 
 
+def test_argmax_rows_matches_torch():
+    from nanovllm import ops
+    torch.manual_seed(5)
+    for T, V in [(1, 8), (3, 1024), (130, 151936), (7, 4104)]:
+        x = torch.randn(T, V, device="cuda", dtype=torch.bfloat16)
+        assert torch.equal(ops.argmax_rows(x), x.float().argmax(-1))
+    x = torch.zeros(4, 4096, device="cuda", dtype=torch.bfloat16)
+    x[0, 77] = x[0, 3000] = 5.0                     # ties: the smallest index
+    x[1, 4095] = 1.0
+    x[2, :] = -3.0
+    x[3, 10] = float("nan"); x[3, 20] = 0.5         # NaN never wins
+    assert ops.argmax_rows(x).tolist() == [77, 4095, 0, 20]
+
+
 def _rope_ref(x, pos, cos_sin):
     cs = cos_sin[pos]                                   # [T, 128]
     cos, sin = cs[:, None, :64], cs[:, None, 64:]
