@@ -111,6 +111,17 @@ static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_byte
         p.counters = (unsigned*)ws;
         p.partial = (unsigned char*)ws + kCounterBytes;
     }
+    // XCD-aware tile order for grids of many tiles per XCD (prefill): the XCD grouping along N that keeps an
+    // XCD's weight slice within about half of its 4 MiB L2
+    p.swz_gn = 0;
+    if (pl.split == 1 && pl.grid.x * pl.grid.y >= 512 && !getenv("QL_NO_XCD_SWIZZLE")) {
+        const uint64_t wbytes = (uint64_t)p.N * p.K;
+        for (int gn = 1; gn <= 8; gn *= 2) {
+            if (pl.grid.x % gn || pl.grid.y % (8 / gn)) continue;
+            p.swz_gn = gn;
+            if (wbytes / gn <= (2u << 20)) break;
+        }
+    }
     hipLaunchKernelGGL(k, pl.grid, dim3(64 * pl.wn * pl.wk), 0, s, p);
     QL_CHECK_LAUNCH(fn);
     return QL_OK;

@@ -52,6 +52,7 @@ struct GemmParams {
     int k_per_split;             // multiple of the block's K chunk
     int bias_after_round;        // 1: bf16(bf16(v) + b)   0: bf16(v + b)
     int silu;                    // 1: weight rows alternate 32-row strips of gate and up; y[M, N/2] = silu(gate) * up
+    int swz_gn;                  // 0, or the number of XCD groups along N (1, 2, 4, 8) of the XCD-aware tile order
 };
 
 typedef void (*kern_t)(const GemmParams);
@@ -153,8 +154,20 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    const int m0 = blockIdx.y * C::BM;
-    const int n0 = blockIdx.x * C::BN + wn * 32;
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so with the
+    // plain (x = N tile, y = M tile) order every XCD touches every activation tile.  For prefill-sized grids the
+    // host asks for an XCD-aware order instead: the XCDs form a (8/gn) x gn grid over (M tiles, N tiles); one XCD
+    // walks its N tiles fastest, so concurrent workgroups share an activation tile in L2 and the XCD's slice of
+    // the weights (N*K/gn bytes) stays L2-resident.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (p.swz_gn > 0) {          // host guarantees gridDim.x % gn == 0, gridDim.y % (8 / gn) == 0, gridDim.z == 1
+        const unsigned lin = by * gridDim.x + bx, xcd = lin & 7u, idx = lin >> 3;
+        const unsigned gn = (unsigned)p.swz_gn, gm = 8u / gn, ntl = gridDim.x / gn;
+        bx = (xcd % gn) * ntl + idx % ntl;
+        by = (idx / ntl) * gm + xcd / gn;
+    }
+    const int m0 = by * C::BM;
+    const int n0 = bx * C::BN + wn * 32;
     const int k0 = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, k0 + p.k_per_split);
     const int nchunks = (kend - k0 + C::KB - 1) / C::KB;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         }
         if (S > 1) {
             // split-K across workgroups: slab store, ticket, the last arriver sums the slabs in slice order
-            const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned tile = by * gridDim.x + bx;
             raw_t* slab = (raw_t*)p.partial + ((size_t)tile * S) * (WN * MT * 16 * 64) + (size_t)wn * (MT * 16 * 64) + lane;
             raw_t* mine = slab + (size_t)blockIdx.z * (WN * MT * 16 * 64);
             // Partial tiles travel between workgroups (possibly on different XCDs, whose L2s are not
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
                 __syncthreads();                              // every wave is done with the x tile / reduce area
                 unsigned short* ex = (unsigned short*)smem + (size_t)((WKC * (WN / 2) + (wn >> 1)) * MT) * (16 * 64) + lane;
                 const unsigned I = (unsigned)p.N >> 1;
-                const unsigned col = (unsigned)((blockIdx.x * WN + wn) >> 1) * 32u + (unsigned)l31;
+                const unsigned col = (unsigned)((bx * WN + wn) >> 1) * 32u + (unsigned)l31;
                 const unsigned lane_off = (unsigned)(4 * lh) * I + col;
                 // the gate wave finishes registers [R0, R0+RH), the up wave [R0+RH, R0+RN)
                 auto pair = [&](auto upc) {
