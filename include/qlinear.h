@@ -25,6 +25,8 @@ extern "C" {
 /* storage type of quantized values: torch.int8 / torch.float8_e4m3fn (quantization.py:151) */
 #define QL_INT8 0
 #define QL_FP8 1
+/* OR-ed into the weight dtype of the GEMM entry points: qw is in the tiled layout of ql_tile_weight */
+#define QL_TILED 16
 
 /* granularity of the weight scales */
 #define QL_PER_ROW 0    /* sw[N]            (QLinear,       :349-364) */
@@ -66,6 +68,14 @@ int ql_quant_per_group(int dtype, const void* w_bf16, int64_t N, int64_t K, int 
  * QL_PER_GROUP (1,group).  `workspace` >= 16 bytes (used by QL_PER_TENSOR only). */
 int ql_fake_quant(int dtype, int granularity, const void* w_bf16, int64_t N, int64_t K, int group,
                   void* out_bf16, void* workspace, void* stream);
+
+/* Re-arrange a quantized weight qw[N,K] (1 byte per element, row-major) for the GEMM kernels: the 32 columns x
+ * 32 k that one wave loads at a time become one contiguous KiB in lane order,
+ *   out[((n/32) * (K/32) + k/32) * 1024 + ((k%32)/16 * 32 + n%32) * 16 + k%16] = qw[n][k],
+ * rows n >= N of the last strip zero.  `out` holds ceil(N/32)*32*K bytes and must not alias qw.  Done once after
+ * quantizing; the GEMMs then take the buffer with QL_TILED OR-ed into their dtype argument.  A wave load touches
+ * 8 full 128-byte lines instead of 32 quarter-used ones, which is what bounds these kernels.  K % 32 == 0. */
+int ql_tile_weight(const void* qw, void* out, int64_t N, int64_t K, void* stream);
 
 /* ---- fused dequant GEMMs ---------------------------------------------------------------- */
 

@@ -155,6 +155,8 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
 static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, const void* x, const void* qw,
                       const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group,
                       void* workspace, size_t workspace_bytes, void* stream) {
+    const bool tiled = (wdtype & QL_TILED) != 0;
+    wdtype &= ~QL_TILED;
     if ((wdtype != QL_INT8 && wdtype != QL_FP8) || granularity < QL_PER_ROW || granularity > QL_PER_GROUP ||
         (M > 0 && (!x || !y)) || !qw || !sw) {
         set_error("%s: bad argument (wdtype=%d granularity=%d)", fn, wdtype, granularity);
@@ -176,6 +178,7 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     p.sw_stride = granularity == QL_PER_ROW ? 1 : 0;
     p.bias_after_round = granularity == QL_PER_ROW ? 0 : 1;
     p.silu = silu ? 1 : 0;
+    p.wtiled = tiled ? 1 : 0;
     const Plan pl = make_plan(M, N, K, grp, silu);
     kern_t k;
     if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp);
@@ -186,6 +189,8 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
 static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const float* sx, const void* qw,
                      const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, void* workspace,
                      size_t workspace_bytes, void* stream) {
+    const bool tiled = (dtype & QL_TILED) != 0;
+    dtype &= ~QL_TILED;
     if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || !sx || !y)) || !qw || !sw) {
         set_error("%s: bad argument (dtype=%d)", fn, dtype);
         return QL_EINVAL;
@@ -199,6 +204,7 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     p.bias = (const unsigned short*)bias; p.y = (unsigned short*)y; p.partial = nullptr; p.counters = nullptr;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = 0; p.sw_stride = 1; p.bias_after_round = 0;
     p.silu = silu ? 1 : 0;
+    p.wtiled = tiled ? 1 : 0;
     const Plan pl = make_plan(M, N, K, false, silu);
     kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);

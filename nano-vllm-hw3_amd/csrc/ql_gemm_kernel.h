@@ -53,6 +53,7 @@ struct GemmParams {
     int bias_after_round;        // 1: bf16(bf16(v) + b)   0: bf16(v + b)
     int silu;                    // 1: weight rows alternate 32-row strips of gate and up; y[M, N/2] = silu(gate) * up
     int swz_gn;                  // 0, or the number of XCD groups along N (1, 2, 4, 8) of the XCD-aware tile order
+    int wtiled;                  // 1: w is stored as [N/32 strips][K/32 steps][64 lanes][16 bytes] (see ql_tile_weight)
 };
 
 typedef void (*kern_t)(const GemmParams);
@@ -175,7 +176,14 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
 
     // this lane's weight row (clamped: out-of-range columns compute garbage that is never stored)
     const int nrow = min(n0 + l31, p.N - 1);
-    const unsigned woff = (unsigned)nrow * (unsigned)p.K + (unsigned)(16 * lh);   // + uniform k offset per load
+    // Row-major weights: lane (column l31, k half lh) reads 16 bytes of its own row - 32 rows per wave load,
+    // 32 bytes used of every 128-byte line touched.  Tiled weights: the 32 columns x 32 k of one wave load are
+    // stored as one contiguous KiB in lane order, so a load touches 8 full lines instead of 32 partial ones.
+    const unsigned kmul = p.wtiled ? 32u : 1u;                    // bytes the load address advances per k
+    // (a strip past the last one re-reads the last strip, like the clamped row above: never stored)
+    const unsigned wstrip = min((unsigned)(n0 >> 5), (unsigned)((p.N + 31) / 32 - 1));
+    const unsigned woff = p.wtiled ? wstrip * (unsigned)p.K * 32u + (unsigned)lane * 16u
+                                   : (unsigned)nrow * (unsigned)p.K + (unsigned)(16 * lh);   // + uniform k offset per load
 
     // activation staging: thread t moves piece ci = t % CPR of rows row0 + j * RS (j < NP)
     static_assert(C::NT % C::CPR == 0 || C::CPR % C::NT == 0, "staging pattern");
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
     auto load_w1 = [&](auto chk, int kc, int c) -> i32x4 {
         const int kb = kc + wk * C::KW + c * 32;
-        if (!decltype(chk)::value || kb < kend) return gload16(p.w + kb + woff);
+        if (!decltype(chk)::value || kb < kend) return gload16(p.w + kb * kmul + woff);
         return i32x4{0, 0, 0, 0};
     };
     auto load_x = [&](auto chk, int kc) {

@@ -195,6 +195,21 @@ static int stream_grid(int64_t total) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// one thread per 16-byte piece of the tiled layout: piece = (strip * K/32 + kstep) * 64 + lane,
+// lane = 32 * (k half) + column
+__global__ __launch_bounds__(256) void tile_weight_kernel(const unsigned char* __restrict__ qw, unsigned char* __restrict__ out,
+                                                          int64_t N, int64_t K, int64_t pieces) {
+    const int64_t pc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pc >= pieces) return;
+    const int lane = (int)(pc & 63);
+    const int64_t blk = pc >> 6, ksteps = K / 32;
+    const int64_t strip = blk / ksteps, kstep = blk % ksteps;
+    const int64_t n = strip * 32 + (lane & 31), k = kstep * 32 + (lane >> 5) * 16;
+    i32x4 v = {0, 0, 0, 0};
+    if (n < N) v = *(const i32x4*)(qw + n * K + k);
+    *(i32x4*)(out + pc * 16) = v;
+}
+
 }  // namespace ql
 
 using namespace ql;
@@ -306,6 +321,17 @@ int ql_fake_quant(int dtype, int granularity, const void* w, int64_t N, int64_t 
         return QL_EINVAL;
     }
     QL_CHECK_LAUNCH("ql_fake_quant");
+    return QL_OK;
+}
+
+int ql_tile_weight(const void* qw, void* out, int64_t N, int64_t K, void* stream) {
+    if (!qw || !out || N <= 0 || K <= 0 || qw == out) { set_error("ql_tile_weight: bad argument"); return QL_EINVAL; }
+    if (K % 32) { set_error("ql_tile_weight: K=%lld must be a multiple of 32", (long long)K); return QL_ESHAPE; }
+    const int64_t pieces = ((N + 31) / 32) * (K / 32) * 64;          // 16-byte pieces of the output
+    if (pieces > 0x7FFFFFFFll * 256) { set_error("ql_tile_weight: too large"); return QL_ESHAPE; }
+    hipLaunchKernelGGL(tile_weight_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const unsigned char*)qw, (unsigned char*)out, N, K, pieces);
+    QL_CHECK_LAUNCH("ql_tile_weight");
     return QL_OK;
 }
 

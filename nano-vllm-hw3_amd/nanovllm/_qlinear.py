@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QLINEAR_LIB") or os.path.join(_HERE, "_lib", "libqlinear.so")   # env override: A/B builds
 
 QL_INT8, QL_FP8 = 0, 1
+QL_TILED = 16
 QL_PER_ROW, QL_PER_TENSOR, QL_PER_GROUP = 0, 1, 2
 
 _c_vp, _c_i64, _c_int, _c_sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -24,6 +25,7 @@ SIGNATURES = {
     "ql_quant_per_tensor": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp]),
     "ql_quant_per_group": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),
     "ql_fake_quant": (_c_int, [_c_int, _c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),
+    "ql_tile_weight": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_gemm_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_int]),
     "ql_gemm_w8a16": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                _c_int, _c_vp, _c_sz, _c_vp]),

@@ -61,7 +61,7 @@ def save_quantized(model, hf_config_dir: str, out_dir: str):
             m = _quant_meta(mod) + (str(mod.dtype).replace("torch.", ""),)
             assert meta in (None, m), "mixed quantization schemes are not representable"
             meta = m
-            qw, sw, bias = mod.qw, mod.sw, mod.bias
+            qw, sw, bias = mod.rowmajor_qw(), mod.sw, mod.bias
             if mod.silu_fused:
                 qw = deinterleave_gate_up(qw)
                 sw = deinterleave_gate_up(sw) if sw.dim() >= 1 and sw.shape[0] == qw.shape[0] else sw
@@ -163,6 +163,7 @@ def load_quantized(model, path: str, fuse_silu: bool = True):
                     mod = NQ.QLinear.from_quantized(lin, dtype, q, s, b, weight_only=qc["weight_only"])
                 if name == "gate_up_proj" and fuse_silu and (q.shape[0] // 2) % 32 == 0:
                     mod.enable_silu_mul()
+                mod.tile()
                 setattr(getattr(layer, parent), name, mod)
         for name in sorted(keys):
             _assign(model, params, name, f.get_tensor(name))

@@ -84,6 +84,50 @@ def _flatten(x, n_out):
     return x.reshape(-1, x.shape[-1]), y_shape
 
 
+class TiledWeight:
+    """A quantized weight re-arranged by ``tile_weight`` (the layout the kernels load fastest): ``data`` holds
+    ceil(N/32)*32 x K bytes in tile order, ``shape`` is the logical (N, K)."""
+
+    def __init__(self, data, n, k, dtype):
+        self.data, self.shape, self.dtype = data, (n, k), dtype
+        self.device = data.device
+
+    def size(self, i):
+        return self.shape[i]
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def is_contiguous(self):
+        return True
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+    def to_rowmajor(self):
+        """Back to the plain [N, K] tensor (checkpoints store that)."""
+        n, k = self.shape
+        t = self.data.view(torch.uint8).view(-1, k // 32, 2, 32, 16).permute(0, 3, 1, 2, 4).reshape(-1, k)[:n]
+        return t.contiguous().view(self.dtype)
+
+
+@torch.no_grad()
+def tile_weight(qw: torch.Tensor):
+    """qw [N, K] int8 / fp8 (row-major, K % 32 == 0) -> TiledWeight: the 32 columns x 32 k one wave loads at a time
+    stored as one contiguous KiB in lane order.  Accepted by every matmul here in place of qw."""
+    assert qw.dim() == 2 and qw.dtype in _DTYPES and qw.shape[1] % 32 == 0
+    Q.require_cuda(qw, None, "qw")
+    N, K = qw.shape
+    out = torch.empty(((N + 31) // 32 * 32, K), dtype=qw.dtype, device=qw.device)
+    Q.check(Q.load().ql_tile_weight(qw.data_ptr(), out.data_ptr(), N, K, Q.stream_ptr(qw.device)))
+    return TiledWeight(out, N, K, qw.dtype)
+
+
+def _wcode(qw, dtype):
+    return Q.dtype_code(dtype) | (Q.QL_TILED if isinstance(qw, TiledWeight) else 0)
+
+
 def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False):
     assert dtype in _DTYPES and qw.dtype == dtype
     x2, y_shape = _flatten(x, qw.shape[0] // 2 if silu else qw.shape[0])
@@ -99,13 +143,13 @@ def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False):
     lib = Q.load()
     if silu:
         y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=x.device)
-        Q.check(lib.ql_gemm_w8a16_silu(Q.dtype_code(dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
+        Q.check(lib.ql_gemm_w8a16_silu(_wcode(qw, dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
                                        bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                                        group_size or 0, Q.stream_ptr(x.device)))
         return y.view(y_shape)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     ws_ptr, ws_len = Q.workspace.get(x.device, lib.ql_gemm_workspace_bytes(M, N, K, granularity))
-    Q.check(lib.ql_gemm_w8a16(Q.dtype_code(dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
+    Q.check(lib.ql_gemm_w8a16(_wcode(qw, dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
                               bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                               group_size or 0, ws_ptr, ws_len, Q.stream_ptr(x.device)))
     return y.view(y_shape)
@@ -151,13 +195,13 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False):
     lib = Q.load()
     if silu:
         y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=qx.device)
-        Q.check(lib.ql_gemm_w8a8_silu(Q.dtype_code(dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
+        Q.check(lib.ql_gemm_w8a8_silu(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                                       Q.stream_ptr(qx.device)))
         return y if y_shape is None else y.view(y_shape)
     y = torch.empty((M, N), dtype=torch.bfloat16, device=qx.device)
     ws_ptr, ws_len = Q.workspace.get(qx.device, lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW))
-    Q.check(lib.ql_gemm_w8a8(Q.dtype_code(dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
+    Q.check(lib.ql_gemm_w8a8(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
                              bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K, ws_ptr, ws_len,
                              Q.stream_ptr(qx.device)))
     return y if y_shape is None else y.view(y_shape)
@@ -221,7 +265,7 @@ class _QBase(torch.nn.Module):
         """Turn a merged gate/up projection into ``silu(gate) * up``: rearrange the rows once, then every
         forward runs the GEMM with the fused epilogue and returns [..., N/2]."""
         assert self.tp_dim != 1, "a row-parallel linear cannot carry the gate/up epilogue"
-        assert not self.silu_fused
+        assert not self.silu_fused and not isinstance(self.qw, TiledWeight), "interleave before tiling"
         self.qw = interleave_gate_up(self.qw)
         if self.sw.dim() >= 1 and self.sw.shape[0] == self.qw.shape[0]:      # per-row [N] / per-group [N, K/g]
             self.sw = interleave_gate_up(self.sw)
@@ -229,6 +273,16 @@ class _QBase(torch.nn.Module):
             self.bias = interleave_gate_up(self.bias.data)
         self.silu_fused = True
         return self
+
+    def tile(self):
+        """Re-arrange qw into the layout the kernels load fastest (tile_weight); the last step of a conversion,
+        after any gate/up interleave."""
+        if not isinstance(self.qw, TiledWeight) and self.qw.shape[1] % 32 == 0:
+            self.qw = tile_weight(self.qw)
+        return self
+
+    def rowmajor_qw(self):
+        return self.qw.to_rowmajor() if isinstance(self.qw, TiledWeight) else self.qw
 
     def _finish(self, y):
         if self.tp_dim == 1 and self.tp_size > 1:
@@ -403,6 +457,8 @@ def _replace(model, make, fuse_silu=True):
         if fuse_silu and (l.mlp.gate_up_proj.qw.shape[0] // 2) % 32 == 0:
             l.mlp.gate_up_proj.enable_silu_mul()
         l.mlp.down_proj = make(l.mlp.down_proj)
+        for m in (l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj):
+            m.tile()
     _empty_cache()
 
 

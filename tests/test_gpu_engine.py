@@ -415,7 +415,8 @@ def test_quantized_checkpoint_round_trip(tiny_dir, tmp_path, quant):
         for ma, mb in ((x.self_attn.qkv_proj, y.self_attn.qkv_proj), (x.self_attn.o_proj, y.self_attn.o_proj),
                        (x.mlp.gate_up_proj, y.mlp.gate_up_proj), (x.mlp.down_proj, y.mlp.down_proj)):
             assert type(ma) is type(mb) and ma.silu_fused == mb.silu_fused
-            assert torch.equal(ma.qw.view(torch.uint8), mb.qw.view(torch.uint8))
+            assert torch.equal(ma.rowmajor_qw().view(torch.uint8), mb.rowmajor_qw().view(torch.uint8))
+            assert type(ma.qw).__name__ == type(mb.qw).__name__ == "TiledWeight"
             assert torch.equal(ma.sw.float().reshape(-1), mb.sw.float().reshape(-1))
     assert x.mlp.gate_up_proj.silu_fused
     ta = [o["token_ids"] for o in a.generate(_prompts(), sp)]

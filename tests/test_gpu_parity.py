@@ -216,6 +216,57 @@ def test_every_tile_configuration(NQ, tile, split):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+def test_tile_weight_layout_and_round_trip(NQ):
+    """tile_weight against the layout formula of include/qlinear.h (N not a multiple of 32: zero padding) and back."""
+    N, K = 70, 96
+    q = torch.randint(-128, 128, (N, K), dtype=torch.int8, device="cuda")
+    t = NQ.tile_weight(q)
+    assert t.shape == (N, K) and t.data.shape == (96, K)
+    flat = t.data.view(-1).cpu().numpy()
+    qc = q.cpu().numpy()
+    n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+    idx = ((n // 32) * (K // 32) + k // 32) * 1024 + ((k % 32) // 16 * 32 + n % 32) * 16 + k % 16
+    assert np.array_equal(flat[idx], qc)
+    mask = np.ones(flat.size, bool); mask[idx.ravel()] = False
+    assert (flat[mask] == 0).all()
+    assert torch.equal(t.to_rowmajor(), q)
+
+
+@pytest.mark.parametrize("tile", TILES)
+def test_tiled_weights_every_tile(NQ, tile):
+    """The tiled weight layout must give the same results as the row-major one: the int8 W8A8 GEMM and every W8A16
+    variant bit for bit (same tile, same summation order), with M, N and K tails and a ragged split-K."""
+    from nanovllm import _qlinear as Q, ops
+    lib = Q.load()
+    M, N, K = 70, 200, 1184
+    rng = np.random.default_rng(17)
+    x = bf16_t(rand_bf16(rng, (M, K)))
+    w = bf16_t(rand_bf16(rng, (N, K), 0.05))
+    bias = bf16_t(rand_bf16(rng, (N,), 0.5))
+    try:
+        for split in (1, 3):
+            assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], split) == 0
+            for tdt in (torch.int8, torch.float8_e4m3fn):
+                qw, sw = NQ.per_row_quant(w, tdt)
+                tw = NQ.tile_weight(qw)
+                for fn in (NQ.per_row_weight_only_matmul, NQ.per_row_matmul):
+                    assert torch.equal(fn(x, tw, sw, bias, tdt), fn(x, qw, sw, bias, tdt)), (fn.__name__, tdt, tile, split)
+                if tile[0] <= 4:
+                    qg, sg = NQ.per_group_quant(w[:, :1152].contiguous(), 128, tdt)
+                    xg = x[:, :1152].contiguous()
+                    assert torch.equal(NQ.per_group_matmul(xg, NQ.tile_weight(qg), sg, None, 128, tdt),
+                                       NQ.per_group_matmul(xg, qg, sg, None, 128, tdt))
+        if tile[1] % 2 == 0:
+            assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], 1) == 0
+            w2 = bf16_t(rand_bf16(rng, (2 * 160, K), 0.05))
+            qw, sw = NQ.per_row_quant(w2, torch.int8)
+            il = NQ.interleave_gate_up
+            assert torch.equal(NQ.per_row_weight_only_matmul(x, NQ.tile_weight(il(qw)), il(sw), None, torch.int8, silu=True),
+                               ops.silu_mul(NQ.per_row_weight_only_matmul(x, qw, sw, None, torch.int8)))
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
 # ----------------------------------------------------------------------------- fused SiLU * mul epilogue
 @pytest.mark.parametrize("tile", [t for t in TILES if t[1] % 2 == 0])
 def test_fused_silu_epilogue_bit_identical(NQ, tile):

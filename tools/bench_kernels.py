@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--copies", type=int, default=0, help="weight copies cycled (0 = enough to defeat the 256 MiB cache)")
     ap.add_argument("--shapes", default="", help="comma list of shape names to run")
+    ap.add_argument("--tiled", action="store_true", help="weights in the tiled layout (tile_weight)")
     args = ap.parse_args()
     lib = Q.load()
     dev = "cuda"
@@ -84,6 +85,8 @@ def main():
             else:
                 q1, s1 = NQ.per_row_quant(w1, dt)
             qw = q1.unsqueeze(0).repeat(n_copies, 1, 1).contiguous()
+            if args.tiled:
+                qw = [NQ.tile_weight(qw[i]) for i in range(n_copies)]
         for M in [int(m) for m in args.ms.split(",")]:
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
             Q.workspace.reserve(dev, 256 << 20)
