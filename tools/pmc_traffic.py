@@ -25,7 +25,7 @@ def run():
             q, s = NQ.per_row_quant(w, torch.int8)
             if name.endswith("silu"):
                 q, s = NQ.interleave_gate_up(q), NQ.interleave_gate_up(s)
-            ws.append((q, s))
+            ws.append((NQ.tile_weight(q), s))             # the layout the engine's modules use
         for M in MS:
             x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
             for q, s in ws:
