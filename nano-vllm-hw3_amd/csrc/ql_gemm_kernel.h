@@ -230,12 +230,14 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             for (int j = 0; j < C::NP; ++j)
                 sreg[j] = gload16(xs + (size_t)j * RS * p.K * C::AB + off);
         } else {
-            // last row block: rows past M re-read row M-1 (their outputs are never stored)
+            // last row block: rows past M are not fetched (zeros: their outputs are never stored).  All lanes of a
+            // wave hold pieces of the same row whenever a row has at least 64 pieces, so the branch is uniform.
 #pragma unroll
             for (int j = 0; j < C::NP; ++j) {
-                const int gm = min(m0 + st_row0 + j * RS, p.M - 1);
+                const int row = m0 + st_row0 + j * RS;
                 const int k = (kc + st_k < kend) ? kc + st_k : k0;
-                sreg[j] = gload16(p.x + ((size_t)gm * p.K + k) * C::AB);
+                if (row < p.M) sreg[j] = gload16(p.x + ((size_t)row * p.K + k) * C::AB);
+                else sreg[j] = i32x4{0, 0, 0, 0};
             }
         }
     };
