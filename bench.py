@@ -234,14 +234,13 @@ def main():
 
     # record the decode batch size of every step of one pass (for the roofline mix)
     step_batches = []
-    orig_step = llm.step
+    orig_launch = llm.model_runner.launch
 
-    def logged_step():
-        out, n = orig_step()
-        if n < 0:
-            step_batches.append(-n)
-        return out, n
-    llm.step = logged_step
+    def logged_launch(seqs, is_prefill, prev=None):
+        if not is_prefill:
+            step_batches.append(len(seqs))
+        return orig_launch(seqs, is_prefill, prev=prev)
+    llm.model_runner.launch = logged_launch
 
     def sync():
         if world > 1:

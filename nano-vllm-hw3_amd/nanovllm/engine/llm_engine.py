@@ -36,6 +36,7 @@ class LLMEngine:
         self.model_runner = ModelRunner(config, self.rank)
         self.tokenizer = None
         self.scheduler = Scheduler(config)
+        self.pipeline_decode = os.environ.get("NANOVLLM_NO_PIPELINE", "") == ""
 
     def _tok(self):
         if self.tokenizer is None:      # token-id prompts never need a tokenizer
@@ -52,10 +53,18 @@ class LLMEngine:
     def step(self):
         seqs, is_prefill = self.scheduler.schedule()
         token_ids = self.model_runner.run(seqs, is_prefill)
-        self.scheduler.postprocess(seqs, token_ids)
-        outputs = [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+        done = self.scheduler.postprocess(seqs, token_ids)
+        outputs = [(s.seq_id, s.completion_token_ids) for s in done]
         num_tokens = sum(len(s) for s in seqs) if is_prefill else -len(seqs)
         return outputs, num_tokens
+
+    def _can_pipeline(self):
+        """The next step may be launched before the tokens of the one in flight are known if it can only be a
+        decode step over a subset of the same sequences: nothing is waiting for prefill, every running sequence
+        is in every decode step, and there are enough free KV blocks that nothing can be preempted."""
+        sch = self.scheduler
+        return (self.pipeline_decode and not sch.waiting and len(sch.running) <= sch.max_num_seqs and
+                len(sch.block_manager.free) >= len(sch.running))
 
     def is_finished(self):
         return self.scheduler.is_finished()
@@ -66,10 +75,37 @@ class LLMEngine:
         for p, sp in zip(prompts, sampling_params):
             self.add_request(p, sp)
         outputs = {}
-        while not self.is_finished():
-            out, _ = self.step()
-            for seq_id, toks in out:
-                outputs[seq_id] = toks
+        sch, runner = self.scheduler, self.model_runner
+        pending = None                      # (seqs, token indices, handle, covers) of the step in flight
+
+        def drain(p):
+            for s in sch.commit(p[0], p[1], runner.wait(p[2])):
+                outputs[s.seq_id] = s.completion_token_ids
+
+        # Decode steps are pipelined one deep: step i+1 is scheduled and launched while step i runs, its input
+        # ids gathered on the device from step i's sampled tokens, and only then are step i's tokens read on
+        # the host.  The GPU therefore always has the next step queued; results are those of the step-by-step
+        # loop (the reference's llm_engine.py:66-85), an EOS merely ends its sequence one launch later.
+        while True:
+            if pending is not None and not (pending[3] and self._can_pipeline()):
+                drain(pending)
+                pending = None
+            if self.is_finished():
+                if pending is None:
+                    break
+                drain(pending)
+                pending = None
+                continue
+            seqs, is_prefill = sch.schedule()
+            handle = runner.launch(seqs, is_prefill, prev=pending[2] if pending is not None else None)
+            covers = len(seqs) == len(sch.running)      # a later step can only hold sequences of this one
+            idx = sch.advance(seqs)
+            if pending is not None:
+                drain(pending)
+            pending = (seqs, idx, handle, covers)
+            if is_prefill:
+                drain(pending)
+                pending = None
         outs = [outputs[k] for k in sorted(outputs)]
         decode = (lambda t: self.tokenizer.decode(t)) if self.tokenizer is not None else (lambda t: "")
         return [{"text": decode(t), "token_ids": t} for t in outs]

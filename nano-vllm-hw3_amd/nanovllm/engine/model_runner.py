@@ -106,7 +106,7 @@ class ModelRunner:
     def prepare_prefill(self, seqs):
         input_ids, positions, slot_mapping, cu = [], [], [], [0]
         # (re)prefilled sequences may own different blocks than the decode staging rows remember
-        self._stage_rows = [None] * self._stage_max_bs
+        self._stage_rows = [[None] * self._stage_max_bs for _ in range(2)]
         for seq in seqs:
             n = len(seq)
             input_ids.extend(seq.token_ids)
@@ -126,11 +126,11 @@ class ModelRunner:
 
     def _init_decode_staging(self, max_bs, max_blocks):
         """All per-step decode inputs live in ONE int32 device buffer (ids and positions as int64 pairs,
-        slot mapping, context lengths, block tables) mirrored by one pinned host buffer: a decode step
-        costs a single host-to-device copy and no fill or scatter launches.  The hipGraph inputs are
-        views of the device buffer."""
-        words = max_bs * (2 + 2 + 1 + 1 + max_blocks)
-        self._stage_host = torch.zeros(words, dtype=torch.int32, device="cpu", pin_memory=True)
+        slot mapping, context lengths, row permutation, block tables) mirrored by pinned host buffers: a
+        decode step costs a single host-to-device copy and no fill or scatter launches.  The hipGraph
+        inputs are views of the device buffer.  There are TWO host mirrors, used alternately, because a
+        step is prepared while the copy of the step before it may still be queued behind the GPU's work."""
+        words = max_bs * (2 + 2 + 1 + 1 + 1 + max_blocks)
         self._stage_dev = torch.zeros(words, dtype=torch.int32, device=self.device)
 
         def views(buf):
@@ -139,22 +139,37 @@ class ModelRunner:
             pos = buf[o:o + 2 * max_bs].view(torch.int64); o += 2 * max_bs
             slots = buf[o:o + max_bs]; o += max_bs
             ctx = buf[o:o + max_bs]; o += max_bs
+            perm = buf[o:o + max_bs]; o += max_bs
             tables = buf[o:o + max_bs * max_blocks].view(max_bs, max_blocks)
-            return ids, pos, slots, ctx, tables
+            return ids, pos, slots, ctx, tables, perm
         self._stage_max_bs, self._stage_max_blocks = max_bs, max_blocks
-        self._hv = tuple(v.numpy() for v in views(self._stage_host))
+        self._stage_host, self._hvs, self._stage_rows, self._stage_prev_bs = [], [], [], []
+        for _ in range(2):
+            host = torch.zeros(words, dtype=torch.int32, device="cpu", pin_memory=True)
+            hv = tuple(v.numpy() for v in views(host))
+            hv[2].fill(-1)
+            self._stage_host.append(host)
+            self._hvs.append(hv)
+            self._stage_rows.append([None] * max_bs)   # (seq_id, len(block_table)) whose table each row holds
+            self._stage_prev_bs.append(0)
         self._dv = views(self._stage_dev)
-        self._hv[2].fill(-1)
-        self._stage_rows = [None] * max_bs          # (seq_id, len(block_table)) whose table each row holds
-        self._stage_prev_bs = 0
+        self._stage_turn = 0
+        # sampled tokens travel device -> host through pinned buffers, alternately as well
+        self._tok_host = [torch.zeros(max(max_bs, self.config.max_num_seqs), dtype=torch.int64, device="cpu",
+                                      pin_memory=True) for _ in range(2)]
+        self._tok_turn = 0
 
-    def prepare_decode(self, seqs):
-        """Fills the pinned mirror and issues the one copy; returns device views of the first len(seqs)
-        rows.  Rows past the batch keep slot -1 / context 0 (what a padded graph bucket needs)."""
+    def prepare_decode(self, seqs, perm=None):
+        """Fills a pinned mirror and issues the one copy; returns device views of the first len(seqs)
+        rows.  Rows past the batch keep slot -1 / context 0 (what a padded graph bucket needs).
+        ``perm[r]`` = row that sequence r had in the step whose tokens are still on the device."""
         bs = len(seqs)
         if bs > self._stage_max_bs or max(len(s.block_table) for s in seqs) > self._stage_max_blocks:
+            assert perm is None
             return self._prepare_decode_unstaged(seqs)
-        h_ids, h_pos, h_slots, h_ctx, h_tab = self._hv
+        turn = self._stage_turn
+        self._stage_turn = turn ^ 1
+        h_ids, h_pos, h_slots, h_ctx, h_tab, h_perm = self._hvs[turn]
         bsz = self.block_size
         lens = [len(s) for s in seqs]
         h_ids[:bs] = [s.last_token for s in seqs]
@@ -162,19 +177,21 @@ class ModelRunner:
         h_pos[:bs] = h_ctx[:bs]
         h_pos[:bs] -= 1
         h_slots[:bs] = [s.block_table[-1] * bsz + (n - 1) % bsz for s, n in zip(seqs, lens)]
-        prev = self._stage_prev_bs
+        if perm is not None:
+            h_perm[:bs] = perm
+        prev = self._stage_prev_bs[turn]
         if prev > bs:
             h_slots[bs:prev] = -1
             h_ctx[bs:prev] = 0
-        self._stage_prev_bs = bs
-        rows = self._stage_rows
+        self._stage_prev_bs[turn] = bs
+        rows = self._stage_rows[turn]
         for i, s in enumerate(seqs):
             bt = s.block_table
             key = (s.seq_id, len(bt))
             if rows[i] != key:
                 rows[i] = key
                 h_tab[i, :len(bt)] = bt
-        self._stage_dev.copy_(self._stage_host, non_blocking=True)
+        self._stage_dev.copy_(self._stage_host[turn], non_blocking=True)
         d = self._dv
         return d[0][:bs], d[1][:bs], d[2][:bs], d[3][:bs], d[4][:bs]
 
@@ -191,15 +208,26 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ execution
     @torch.inference_mode()
-    def run(self, seqs, is_prefill: bool):
+    def launch(self, seqs, is_prefill: bool, prev=None):
+        """Enqueue one step and the copy of its sampled tokens to the host; returns a handle for wait().
+        ``prev`` = handle of the decode step before this one when its tokens have not been read on the host
+        yet: the input ids of this step are then gathered on the device from that step's output (every
+        sequence of this step must have been part of it), so the host never waits between two steps."""
         if is_prefill:
+            assert prev is None
             ids, pos, cu = self.prepare_prefill(seqs)
             h = self.model(ids, pos)
             last = torch.tensor(cu[1:], device=self.device) - 1
             logits = self.model.compute_logits(h[last].contiguous())
         else:
-            ids, pos, slots, ctx_lens, tables = self.prepare_decode(seqs)
+            perm = None
+            if prev is not None:
+                row = {s.seq_id: i for i, s in enumerate(prev["seqs"])}
+                perm = [row[s.seq_id] for s in seqs]
+            ids, pos, slots, ctx_lens, tables = self.prepare_decode(seqs, perm)
             bs = ids.numel()
+            if prev is not None:
+                torch.index_select(prev["tokens"], 0, self._dv[5][:bs], out=ids)
             if self.enforce_eager or bs > self.max_graph_bs:
                 set_context(AttnContext(False, None, slots, ctx_lens, tables))
                 logits = self.model.compute_logits(self.model(ids, pos))
@@ -211,13 +239,36 @@ class ModelRunner:
         # greedy sampler (layers/sampler.py:10-12)
         if logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0 and logits.is_contiguous():
             from nanovllm import ops
-            token_ids = ops.argmax_rows(logits).tolist()
+            tokens = ops.argmax_rows(logits)
         else:
-            token_ids = logits.argmax(dim=-1).tolist()
-        return token_ids
+            tokens = logits.argmax(dim=-1)
+        n = tokens.numel()
+        if n <= self._tok_host[0].numel():
+            host = self._tok_host[self._tok_turn][:n]
+            self._tok_turn ^= 1
+            host.copy_(tokens, non_blocking=True)
+        else:
+            host = None
+        ev = torch.cuda.Event()
+        ev.record()
+        return dict(seqs=list(seqs), tokens=tokens, host=host, event=ev)
 
-    @torch.inference_mode()
+    @staticmethod
+    def wait(handle):
+        """The token ids of a launched step (blocks until the GPU has produced them)."""
+        if handle["host"] is None:
+            return handle["tokens"].tolist()
+        handle["event"].synchronize()
+        return handle["host"].tolist()
+
+    def run(self, seqs, is_prefill: bool):
+        return self.wait(self.launch(seqs, is_prefill))
+
+    @torch.no_grad()
     def capture_graphs(self):
+        # (no_grad, not inference_mode: the first capture of a process creates the RNG bookkeeping tensors that
+        # every later capture updates in place, and as inference tensors they would make a capture that anybody
+        # starts outside inference mode fail for as long as these graphs live)
         cfg, hf = self.config, self.config.hf_config
         max_bs = min(cfg.max_num_seqs, 512)
         self.max_graph_bs = max_bs

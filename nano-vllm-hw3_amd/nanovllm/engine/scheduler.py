@@ -57,10 +57,45 @@ class Scheduler:
         self.block_manager.deallocate(seq)
         self.waiting.appendleft(seq)
 
+    PENDING = 0   # stands in for a token that the GPU is still computing
+
+    def _finish(self, seq):
+        seq.status = SequenceStatus.FINISHED
+        self.block_manager.deallocate(seq)
+        self.running.remove(seq)
+
+    def advance(self, seqs):
+        """Account for the token every sequence of a launched step will receive, before its value is known:
+        lengths, block tables and the max_tokens limit only depend on the COUNT of tokens, so the next step
+        can be scheduled while this one runs.  Returns the index each token will occupy."""
+        idx = []
+        for seq in seqs:
+            idx.append(seq.num_tokens)
+            seq.append_token(self.PENDING)
+            if seq.num_completion_tokens == seq.max_tokens:
+                self._finish(seq)
+        return idx
+
+    def commit(self, seqs, idx, token_ids):
+        """Fill in the tokens of a step that advance() accounted for; returns the sequences whose output is
+        complete.  An EOS ends its sequence one step late when the next step was launched before the EOS
+        reached the host: that step's token (beyond the EOS) is dropped."""
+        done = []
+        for seq, i, tok in zip(seqs, idx, token_ids):
+            if i >= seq.num_tokens:            # cut off by an EOS of an earlier step
+                continue
+            seq.token_ids[i] = tok
+            if i == seq.num_tokens - 1:
+                seq.last_token = tok
+            if not seq.ignore_eos and tok == self.eos:
+                del seq.token_ids[i + 1:]
+                seq.num_tokens = i + 1
+                seq.last_token = tok
+                if not seq.is_finished:
+                    self._finish(seq)
+            if seq.is_finished and i == seq.num_tokens - 1:
+                done.append(seq)
+        return done
+
     def postprocess(self, seqs, token_ids):
-        for seq, tok in zip(seqs, token_ids):
-            seq.append_token(tok)
-            if (not seq.ignore_eos and tok == self.eos) or seq.num_completion_tokens == seq.max_tokens:
-                seq.status = SequenceStatus.FINISHED
-                self.block_manager.deallocate(seq)
-                self.running.remove(seq)
+        return self.commit(seqs, self.advance(seqs), token_ids)

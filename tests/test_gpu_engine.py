@@ -294,6 +294,43 @@ def test_scheduler_continuous_batching_and_finish(tiny_dir):
     assert [len(o["token_ids"]) for o in out] == [3 + i for i in range(9)]
 
 
+def test_pipelined_decode_matches_step_by_step(tiny_dir):
+    """Launching step i+1 before step i's tokens reach the host (input ids gathered on the device) gives the
+    outputs of the step-by-step loop: different lengths (rows leave the batch at different steps), and with a
+    live EOS, which ends its sequence one launch late and must drop the token launched beyond it."""
+    from nanovllm import LLM, SamplingParams
+    llm = LLM(tiny_dir, load_format="dummy", enforce_eager=False, max_model_len=512, max_num_seqs=16,
+              quant_type="per_row_weight_only", linear_dtype=torch.int8)
+    prompts = _prompts(12)
+    sps = [SamplingParams(max_tokens=5 + 3 * i, ignore_eos=True) for i in range(12)]
+    launches = []
+    orig = llm.model_runner.launch
+    llm.model_runner.launch = lambda seqs, is_prefill, prev=None: (launches.append(prev is not None), orig(seqs, is_prefill, prev=prev))[1]
+    llm.pipeline_decode = True
+    piped = [o["token_ids"] for o in llm.generate(prompts, sps)]
+    assert sum(launches) >= 30, "decode steps were not pipelined"
+    llm.pipeline_decode = False
+    launches.clear()
+    plain = [o["token_ids"] for o in llm.generate(prompts, sps)]
+    assert not any(launches)
+    assert piped == plain and [len(t) for t in plain] == [5 + 3 * i for i in range(12)]
+    # a token that some sequence produces in the middle of its output becomes the EOS
+    eos = next(t[len(t) // 2] for t in plain if len(t) >= 8)
+    llm.scheduler.eos = eos
+    sps = [SamplingParams(max_tokens=5 + 3 * i, ignore_eos=False) for i in range(12)]
+    outs = []
+    for mode in (True, False):
+        llm.pipeline_decode = mode
+        outs.append([o["token_ids"] for o in llm.generate(prompts, sps)])
+    assert outs[0] == outs[1]
+    for full, cut in zip(plain, outs[0]):
+        want = full[:full.index(eos) + 1] if eos in full else full
+        assert cut == want
+    assert any(len(c) < len(f) for f, c in zip(plain, outs[0]))
+    assert len(llm.scheduler.block_manager.free) == llm.scheduler.block_manager.num_blocks
+    llm.model_runner.launch = orig
+
+
 def test_rccl_allreduce_on_side_stream_is_graph_capturable():
     """The row-parallel reduction (RCCL all-reduce enqueued on a side HIP stream with event fork/join)
     must be capturable into the decode hipGraph.  One GPU here, so the group has a single rank; the
