@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--dtype", default="int8", choices=["int8", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--max-model-len", type=int, default=4096, help="4096 = the reference bench; other values are experiments")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +223,7 @@ def main():
     model_dir = tempfile.mkdtemp(prefix=f"qwen3_06b_r{rank}_")
     with open(os.path.join(model_dir, "config.json"), "w") as f:
         json.dump(QWEN3_06B, f)
-    kw = dict(enforce_eager=False, max_model_len=4096, load_format="dummy", tensor_parallel_size=world)
+    kw = dict(enforce_eager=False, max_model_len=args.max_model_len, load_format="dummy", tensor_parallel_size=world)
     if args.quant != "bf16":
         kw.update(quant_type=args.quant, linear_dtype=torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn,
                   group_size=128)

@@ -139,6 +139,13 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k);
 int ql_add_rmsnorm(const void* x_bf16, const void* residual_bf16, const void* weight_bf16, float eps,
                    void* out_bf16, void* residual_out_bf16, int64_t T, int64_t H, void* stream);
 
+/* ql_add_rmsnorm with the dynamic per-row activation quantization of the W8A8 linear that consumes the
+ * normalised row folded in (per_row_quant on x at nanovllm/utils/quantization.py:323, kernel :13-51):
+ * q[T,H] (dtype QL_INT8 / QL_FP8) and scale[T] are bit-identical to ql_add_rmsnorm followed by
+ * ql_quant_per_row; the bf16 normalised row is never written.  residual as above. */
+int ql_add_rmsnorm_quant(int dtype, const void* x_bf16, const void* residual_bf16, const void* weight_bf16, float eps,
+                         void* q, float* scale, void* residual_out_bf16, int64_t T, int64_t H, void* stream);
+
 /* SiluAndMul.forward (nanovllm/layers/activation.py:11-14): out[T,I] = silu(x[:, :I]) * x[:, I:]. */
 int ql_silu_mul(const void* x_bf16, void* out_bf16, int64_t T, int64_t I, void* stream);
 

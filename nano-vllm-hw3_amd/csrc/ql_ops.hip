@@ -14,13 +14,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- y = RMSNorm(x [+ residual]) * w ; residual_out = bf16(x + residual) ------------------------
 // One workgroup per row; the row stays in registers between the two passes (H <= 8192).
-template <int NV>   // 16-byte vectors per thread
+// QDT = QL_INT8 / QL_FP8: the normalised row is not stored as bf16 but quantized per row (dynamic
+// activation quantization of the W8A8 linears, the reference's per_row_quant on x): q = cast(y * Q / max|y|),
+// scale = max|y| / Q with y the bf16 values the plain kernel would have stored, so (q, scale) are bit-identical
+// to ql_add_rmsnorm followed by ql_quant_per_row, without the launch and the bf16 round trip in between.
+template <int NV, int QDT>   // 16-byte vectors per thread
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* __restrict__ x,
                                                           const unsigned short* __restrict__ res,
                                                           const unsigned short* __restrict__ w,
                                                           unsigned short* __restrict__ out,
-                                                          unsigned short* __restrict__ res_out, int H, float eps) {
-    __shared__ float sh[4];
+                                                          unsigned short* __restrict__ res_out, int H, float eps,
+                                                          unsigned char* __restrict__ q_out,
+                                                          float* __restrict__ scale_out) {
+    __shared__ float sh[8];
     const size_t row = blockIdx.x;
     const int nvec = H >> 3;
     float v[NV][8];
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
     __syncthreads();
     ss = sh[0] + sh[1] + sh[2] + sh[3];
     const float inv = rsqrtf(ss / (float)H + eps);
+    float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = threadIdx.x + 256 * j;
@@ -61,7 +68,40 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 o[k] = f32_to_bf16_bits(round_to_bf16(v[j][k] * inv) * bf16_bits_to_f32(ww[k]));
-            *(u16x8*)(out + row * H + c * 8) = o;
+            if constexpr (QDT < 0) {
+                *(u16x8*)(out + row * H + c * 8) = o;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[j][k] = bf16_bits_to_f32(o[k]);
+                    amax = fmaxf(amax, fabsf(v[j][k]));
+                }
+            }
+        }
+    }
+    if constexpr (QDT >= 0) {
+        constexpr float QMAX = (QDT == QL_INT8) ? 127.f : 448.f;
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) sh[4 + (threadIdx.x >> 6)] = amax;
+        __syncthreads();
+        const float row_max = fmaxf(fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7])), 1e-8f);
+        const float sc_inv = QMAX / row_max;
+        if (threadIdx.x == 0) scale_out[row] = row_max / QMAX;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < nvec) {
+                unsigned long long o8 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float y = v[j][k] * sc_inv;
+                    unsigned b;
+                    if (QDT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)roundf(y);
+                    else b = f32_to_e4m3fn(y);
+                    o8 |= (unsigned long long)b << (8 * k);
+                }
+                *(unsigned long long*)(q_out + row * H + c * 8) = o8;
+            }
         }
     }
 }
@@ -340,24 +380,42 @@ using namespace ql;
 
 extern "C" {
 
-int ql_add_rmsnorm(const void* x, const void* residual, const void* weight, float eps, void* out, void* residual_out,
-                   int64_t T, int64_t H, void* stream) {
-    if (!weight || T < 0 || H <= 0 || (T > 0 && (!x || !out)) || (residual && !residual_out)) {
-        set_error("ql_add_rmsnorm: bad argument");
+static int add_rmsnorm_launch(const char* fn, int qdt, const void* x, const void* residual, const void* weight, float eps,
+                              void* out, void* residual_out, void* q_out, float* scale_out, int64_t T, int64_t H,
+                              void* stream) {
+    if (!weight || T < 0 || H <= 0 || (T > 0 && !x) || (residual && !residual_out) ||
+        (T > 0 && (qdt < 0 ? !out : (!q_out || !scale_out)))) {
+        set_error("%s: bad argument", fn);
         return QL_EINVAL;
     }
-    if (H % 8 || H > 8192) { set_error("ql_add_rmsnorm: H=%lld must be a multiple of 8 and <= 8192", (long long)H); return QL_ESHAPE; }
+    if (qdt >= 0 && qdt != QL_INT8 && qdt != QL_FP8) { set_error("%s: dtype=%d", fn, qdt); return QL_EINVAL; }
+    if (H % 8 || H > 8192) { set_error("%s: H=%lld must be a multiple of 8 and <= 8192", fn, (long long)H); return QL_ESHAPE; }
     if (T == 0) return QL_OK;
-    if (T > 0x7FFFFFFF) { set_error("ql_add_rmsnorm: T too large"); return QL_ESHAPE; }
+    if (T > 0x7FFFFFFF) { set_error("%s: T too large", fn); return QL_ESHAPE; }
     const int nv = (int)((H / 8 + 255) / 256);
     dim3 grid((unsigned)T), block(256);
     hipStream_t s = as_stream(stream);
-#define QL_RMS(NV) hipLaunchKernelGGL(add_rmsnorm_kernel<NV>, grid, block, 0, s, (const unsigned short*)x, \
-        (const unsigned short*)residual, (const unsigned short*)weight, (unsigned short*)out, (unsigned short*)residual_out, (int)H, eps)
-    if (nv == 1) QL_RMS(1); else if (nv == 2) QL_RMS(2); else QL_RMS(4);
+#define QL_RMS(NV, QDT) hipLaunchKernelGGL((add_rmsnorm_kernel<NV, QDT>), grid, block, 0, s, (const unsigned short*)x, \
+        (const unsigned short*)residual, (const unsigned short*)weight, (unsigned short*)out, (unsigned short*)residual_out, \
+        (int)H, eps, (unsigned char*)q_out, scale_out)
+#define QL_RMS_NV(QDT) do { if (nv == 1) QL_RMS(1, QDT); else if (nv == 2) QL_RMS(2, QDT); else QL_RMS(4, QDT); } while (0)
+    if (qdt < 0) QL_RMS_NV(-1); else if (qdt == QL_INT8) QL_RMS_NV(QL_INT8); else QL_RMS_NV(QL_FP8);
+#undef QL_RMS_NV
 #undef QL_RMS
-    QL_CHECK_LAUNCH("ql_add_rmsnorm");
+    QL_CHECK_LAUNCH(fn);
     return QL_OK;
+}
+
+int ql_add_rmsnorm(const void* x, const void* residual, const void* weight, float eps, void* out, void* residual_out,
+                   int64_t T, int64_t H, void* stream) {
+    return add_rmsnorm_launch("ql_add_rmsnorm", -1, x, residual, weight, eps, out, residual_out, nullptr, nullptr, T, H,
+                              stream);
+}
+
+int ql_add_rmsnorm_quant(int dtype, const void* x, const void* residual, const void* weight, float eps, void* q_out,
+                         float* scale_out, void* residual_out, int64_t T, int64_t H, void* stream) {
+    return add_rmsnorm_launch("ql_add_rmsnorm_quant", dtype, x, residual, weight, eps, nullptr, residual_out, q_out,
+                              scale_out, T, H, stream);
 }
 
 int ql_silu_mul(const void* x, void* out, int64_t T, int64_t I, void* stream) {

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ql_gemm_w8a8_silu": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ql_gemm_force_config": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "ql_add_rmsnorm": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    "ql_add_rmsnorm_quant": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_silu_mul": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_qknorm_rope_store": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),

@@ -112,9 +112,9 @@ class Qwen3Attention(nn.Module):
         self.cos_sin = cos_sin
         self.k_cache = self.v_cache = torch.tensor([])
 
-    def forward(self, positions, hidden_states):
+    def forward(self, positions, hidden_states, quantized=None):
         ctx = get_context()
-        qkv = self.qkv_proj(hidden_states)
+        qkv = self.qkv_proj(hidden_states) if quantized is None else self.qkv_proj.forward_quantized(*quantized)
         qw = self.q_norm.weight if not self.qkv_bias else None
         kw = self.k_norm.weight if not self.qkv_bias else None
         q, k, v = ops.qknorm_rope_store(qkv, positions, self.cos_sin, qw, kw, self.eps, self.num_heads,
@@ -138,8 +138,8 @@ class Qwen3MLP(nn.Module):
         self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=False)
         self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False)
 
-    def forward(self, x):
-        h = self.gate_up_proj(x)
+    def forward(self, x, quantized=None):
+        h = self.gate_up_proj(x) if quantized is None else self.gate_up_proj.forward_quantized(*quantized)
         if not getattr(self.gate_up_proj, "silu_fused", False):   # else the GEMM epilogue already applied SiLU * mul
             h = ops.silu_mul(h)
         return self.down_proj(h)
@@ -154,11 +154,23 @@ class Qwen3DecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
 
     def forward(self, positions, hidden_states, residual):
-        if residual is None:
-            hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
+        # A W8A8 linear (dynamic per-row activation quantization) takes its input already quantized: the
+        # RMSNorm launch in front of it emits (q, scale) directly instead of the bf16 row.
+        qkv, gate_up = self.self_attn.qkv_proj, self.mlp.gate_up_proj
+        if getattr(qkv, "takes_quantized_input", False) and hidden_states.dim() == 2:
+            q, s, residual = ops.add_rmsnorm_quant(hidden_states, residual, self.input_layernorm.weight,
+                                                   self.input_layernorm.eps, qkv.dtype)
+            hidden_states = self.self_attn(positions, None, quantized=(q, s))
         else:
-            hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(positions, hidden_states)
+            if residual is None:
+                hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
+            else:
+                hidden_states, residual = self.input_layernorm(hidden_states, residual)
+            hidden_states = self.self_attn(positions, hidden_states)
+        if getattr(gate_up, "takes_quantized_input", False) and hidden_states.dim() == 2:
+            q, s, residual = ops.add_rmsnorm_quant(hidden_states, residual, self.post_attention_layernorm.weight,
+                                                   self.post_attention_layernorm.eps, gate_up.dtype)
+            return self.mlp(None, quantized=(q, s)), residual
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         return self.mlp(hidden_states), residual
 

@@ -24,6 +24,25 @@ def add_rmsnorm(x, residual, weight, eps):
     return out, res_out
 
 
+def add_rmsnorm_quant(x, residual, weight, eps, dtype):
+    """add_rmsnorm + per-row activation quantization in one launch: returns (q, scale, new_residual) with
+    (q, scale) bit-identical to per_row_quant(add_rmsnorm(...)[0], dtype)."""
+    Q.require_cuda(x, BF16, "x")
+    H = x.shape[-1]
+    T = x.numel() // H
+    q = torch.empty((T, H), dtype=dtype, device=x.device)
+    scale = torch.empty((T,), dtype=torch.float32, device=x.device)
+    res_out = None
+    if residual is not None:
+        Q.require_cuda(residual, BF16, "residual")
+        res_out = torch.empty_like(x)
+    Q.check(Q.load().ql_add_rmsnorm_quant(Q.dtype_code(dtype), x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                          weight.data_ptr(), eps, q.data_ptr(), scale.data_ptr(),
+                                          res_out.data_ptr() if res_out is not None else None, T, H,
+                                          Q.stream_ptr(x.device)))
+    return q, scale, (x if residual is None else res_out)
+
+
 def silu_mul(x):
     Q.require_cuda(x, BF16, "x")
     I = x.shape[-1] // 2

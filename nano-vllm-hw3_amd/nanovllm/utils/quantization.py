@@ -325,6 +325,17 @@ class QLinear(_QBase):
         fn = per_row_weight_only_matmul if self.weight_only else per_row_matmul
         return self._finish(fn(x, self.qw, self.sw, self._bias_for_rank(), self.dtype, self.silu_fused))
 
+    @property
+    def takes_quantized_input(self):
+        """True for the W8A8 form: the caller may quantize the activations itself (e.g. inside the preceding
+        RMSNorm launch, ops.add_rmsnorm_quant) and call forward_quantized."""
+        return not self.weight_only
+
+    def forward_quantized(self, qx: torch.Tensor, sx: torch.Tensor):
+        """forward() on activations already quantized per row: qx [M, K] in self.dtype, sx [M] f32."""
+        assert not self.weight_only
+        return self._finish(w8a8_matmul(qx, sx, self.qw, self.sw, self._bias_for_rank(), self.dtype, None, self.silu_fused))
+
 
 class QTensorLinear(_QBase):
     """Per-tensor quantized Linear layer (reference: quantization.py:367-382)."""

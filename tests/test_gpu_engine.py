@@ -52,6 +52,31 @@ def test_add_rmsnorm_matches_torch():
         assert res2 is x
 
 
+@pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn])
+def test_add_rmsnorm_quant_equals_norm_then_per_row_quant(dtype):
+    """The W8A8 prologue fusion: (q, scale) bit-identical to the two separate launches (and so to the oracle's
+    per_row_quant of the normalised row, which the parity suite pins); all-zero rows hit the 1e-8 floor."""
+    from nanovllm import ops
+    from nanovllm.utils import quantization as NQ
+    torch.manual_seed(6)
+    for T, H in [(1, 128), (7, 1024), (130, 1024), (33, 4096), (3, 8192)]:
+        x = torch.randn(T, H, device="cuda", dtype=torch.bfloat16) * 3
+        r = torch.randn(T, H, device="cuda", dtype=torch.bfloat16)
+        if T > 2:
+            x[2] = 0
+            r[2] = 0
+        w = (1 + 0.1 * torch.randn(H, device="cuda")).to(torch.bfloat16)
+        for res in (r, None):
+            out, res_ref = ops.add_rmsnorm(x, res, w, 1e-6)
+            q_ref, s_ref = NQ.per_row_quant(out, dtype)
+            q, s, res_out = ops.add_rmsnorm_quant(x, res, w, 1e-6, dtype)
+            assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s, s_ref)
+            if res is None:
+                assert res_out is x
+            else:
+                assert torch.equal(res_out, res_ref)
+
+
 def test_silu_mul_matches_torch():
     from nanovllm import ops
     torch.manual_seed(1)
