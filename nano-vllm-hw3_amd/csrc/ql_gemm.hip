@@ -67,8 +67,11 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     const int64_t base = mblocks * nblocks;
     // fewer tiles than CUs even at 32 x 32 (N = hidden size): split K so that each slice is one 1024-k
     // chunk, combined in-kernel by the last arriver (measured: down_proj 11.1 -> 9.5 us at M = 64..128)
+    // (K >= 8192 is cut into 2048-k slices instead: two chunks per slice halve the slab traffic, measured on the
+    // Qwen3-4B down_proj shape; a grid of 144+ tiles of the 64 x 128 tile is not split at all)
     int64_t split = 1;
-    if (base < 160) split = (K + 1023) / 1024;
+    if (base < 144) split = K >= 8192 ? (K + 2047) / 2048 : (K + 1023) / 1024;
+    else if (base < 160 && pick < nladder - 1) split = (K + 1023) / 1024;
     else if (base < 512 && K >= 4096) split = (K + 4095) / 4096;   // long K: at most four chunks per slice
     if (f_split > 0) split = f_split;
     if (silu) split = 1;                                    // gate and up meet in the epilogue of ONE workgroup
