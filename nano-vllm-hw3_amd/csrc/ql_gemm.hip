@@ -53,8 +53,8 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     if (M > 1024) {
         mt = 2; wn = 4; wk = 1; cp = 4;
         // with enough 128 x 256 tiles to fill the chip, the wide 8-wave tile halves the L2->LDS bytes
-        // per MFMA (measured +25 % at M = 16384)
-        if (!group && ((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = 2; }
+        // per MFMA (measured +25 % at M = 16384); 128-k chunks give its loads a whole chunk of MFMAs to land
+        if (!group && ((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = 4; }
     }
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group) && !(silu && (f_wn & 1))) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     }
 
     constexpr int D = DB ? CP : (CP < 8 ? CP : 8);               // weight loads in flight per lane
-    i32x4 wcur[D], wnext[DB ? CP : 1], sreg[C::NP];
+    i32x4 wcur[D], wnext[(DB && WN != 8) ? CP : 1], sreg[C::NP];
 
     // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
     auto load_w1 = [&](auto chk, int kc, int c) -> i32x4 {
@@ -307,21 +307,42 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     };
 
     // one chunk, CHK = the slice may end inside this chunk (per-step bounds tests needed)
+    // RING (the 8-strip prefill tiles, which live at the register limit): the weights of step c of the NEXT
+    // chunk are requested as soon as step c of this chunk has taken its register, so one chunk of weight loads
+    // is in flight with CP registers instead of 2 CP, which is what lets the 128 x 256 tile run 128-k chunks
+    // without spilling (+8-10 % at M = 16384 over 64-k chunks).  The address is clamped into the slice instead
+    // of branching around the load (past the end the last step is re-read and never used: step() skips it).
+    constexpr bool RING = DB && WN == 8;
+    auto load_w_ring = [&](int kc, int c) -> i32x4 {
+        const int kb = min(kc + wk * C::KW + c * 32, kend - 32);
+        return gload16(p.w + kb * kmul + woff);
+    };
     auto chunk_db = [&](auto chk, int it) {
         const int kc = k0 + it * C::KB;
         const int buf = it & 1;
         const bool more = (it + 1) < nchunks;
-        if (more) {
+        if constexpr (RING) {
+            if (more) load_x(TrueT{}, kc + C::KB);
 #pragma unroll
-            for (int c = 0; c < CP; ++c) wnext[c] = load_w1(TrueT{}, kc + C::KB, c);
-            load_x(TrueT{}, kc + C::KB);
-        }
+            for (int c = 0; c < CP; ++c) {
+                const i32x4 w = wcur[c];
+                wcur[c] = load_w_ring(kc + C::KB, c);
+                step(chk, buf, kc, c, w);
+            }
+            if (more) store_x(buf ^ 1);
+        } else {
+            if (more) {
 #pragma unroll
-        for (int c = 0; c < CP; ++c) step(chk, buf, kc, c, wcur[c]);
-        if (more) {
-            store_x(buf ^ 1);
+                for (int c = 0; c < CP; ++c) wnext[c] = load_w1(TrueT{}, kc + C::KB, c);
+                load_x(TrueT{}, kc + C::KB);
+            }
 #pragma unroll
-            for (int c = 0; c < CP; ++c) wcur[c] = wnext[c];
+            for (int c = 0; c < CP; ++c) step(chk, buf, kc, c, wcur[c]);
+            if (more) {
+                store_x(buf ^ 1);
+#pragma unroll
+                for (int c = 0; c < CP; ++c) wcur[c] = wnext[c];
+            }
         }
         __syncthreads();
     };
@@ -542,7 +563,7 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(1, 2, 4, 8, false) X(1, 2, 4, 4, true) X(2, 2, 4, 8, false) X(2, 2, 4, 4, true) X(1, 1, 8, 4, false)     \
     X(2, 4, 2, 4, true) X(4, 4, 2, 4, true)                                                          \
     X(1, 4, 1, 32, false) X(1, 4, 2, 16, false) X(2, 4, 2, 16, false) X(1, 2, 4, 16, false) X(1, 1, 8, 8, false) \
-    X(4, 8, 1, 2, true)
+    X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)
 #define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these

@@ -177,7 +177,7 @@ def test_w8a8_reference_selftest_tolerance(NQ):
 TILES = [(1, 1, 4, 2), (1, 1, 4, 4), (1, 1, 4, 8), (2, 1, 4, 2), (2, 1, 4, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4),
          (8, 4, 1, 4), (2, 2, 2, 2), (2, 2, 2, 4), (2, 2, 2, 8), (4, 2, 2, 2), (4, 2, 2, 4),
          (1, 2, 4, 8), (1, 2, 4, 4), (2, 2, 4, 8), (2, 2, 4, 4), (1, 1, 8, 4), (2, 4, 2, 4), (4, 4, 2, 4),
-         (1, 4, 1, 32), (1, 4, 2, 16), (2, 4, 2, 16), (1, 2, 4, 16), (1, 1, 8, 8), (4, 8, 1, 2)]
+         (1, 4, 1, 32), (1, 4, 2, 16), (2, 4, 2, 16), (1, 2, 4, 16), (1, 1, 8, 8), (4, 8, 1, 2), (4, 8, 1, 4)]
 
 
 @pytest.mark.parametrize("tile", TILES)

@@ -25,7 +25,7 @@ SHAPES = {
 TILES = [(1, 1, 4, 2), (1, 1, 4, 4), (1, 1, 4, 8), (2, 1, 4, 2), (2, 1, 4, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4),
          (8, 4, 1, 4), (2, 2, 2, 2), (2, 2, 2, 4), (2, 2, 2, 8), (4, 2, 2, 2), (4, 2, 2, 4),
          (1, 2, 4, 8), (1, 2, 4, 4), (2, 2, 4, 8), (2, 2, 4, 4), (1, 1, 8, 4), (2, 4, 2, 4), (4, 4, 2, 4),
-         (1, 4, 1, 32), (1, 4, 2, 16), (2, 4, 2, 16), (1, 2, 4, 16), (1, 1, 8, 8), (4, 8, 1, 2)]
+         (1, 4, 1, 32), (1, 4, 2, 16), (2, 4, 2, 16), (1, 2, 4, 16), (1, 1, 8, 8), (4, 8, 1, 2), (4, 8, 1, 4)]
 
 
 def time_fn(fn, n_copies, iters):
@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--copies", type=int, default=0, help="weight copies cycled (0 = enough to defeat the 256 MiB cache)")
     ap.add_argument("--shapes", default="", help="comma list of shape names to run")
+    ap.add_argument("--tiles", default="", help="with --sweep: only these tiles, e.g. 4.8.1.2,4.8.1.4")
+    ap.add_argument("--splits", default="1,2,4,8")
     ap.add_argument("--tiled", action="store_true", help="weights in the tiled layout (tile_weight)")
     args = ap.parse_args()
     lib = Q.load()
@@ -102,7 +104,9 @@ def main():
             iters = args.iters if M <= 2048 else max(10, args.iters // 10)
             cfgs = [None]
             if args.sweep and args.mode != "bf16":
-                cfgs += [(t, s) for t in TILES for s in (1, 2, 4, 8) if not (args.mode == "group" and t[0] == 8)]
+                tiles = [tuple(int(v) for v in t.split(".")) for t in args.tiles.split(",")] if args.tiles else TILES
+                cfgs += [(t, s) for t in tiles for s in [int(v) for v in args.splits.split(",")]
+                         if not (args.mode == "group" and t[0] == 8)]
             best = None
             for cfg in cfgs:
                 if cfg is not None:
