@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--dtype", default="int8", choices=["int8", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--quant-lm-head", action="store_true", help="opt-in int8 LM head (not the reference's numerics)")
     ap.add_argument("--max-model-len", type=int, default=4096, help="4096 = the reference bench; other values are experiments")
     args = ap.parse_args()
 
@@ -227,6 +228,8 @@ def main():
     if args.quant != "bf16":
         kw.update(quant_type=args.quant, linear_dtype=torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn,
                   group_size=128)
+    if args.quant_lm_head:
+        kw.update(quantize_lm_head=True)
     llm = LLM(model_dir, **kw)
 
     prompts, max_tokens = workload()

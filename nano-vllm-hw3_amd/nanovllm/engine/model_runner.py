@@ -71,6 +71,9 @@ class ModelRunner:
                 w = getattr(m, "qw", None)
                 if w is not None:
                     shapes.add((w.shape[0], w.shape[1]))
+        head = getattr(self.model.lm_head, "quantized", None)
+        if head is not None:
+            shapes.add((head.qw.shape[0], head.qw.shape[1]))
         return sorted(shapes)
 
     def _reserve_gemm_workspace(self):

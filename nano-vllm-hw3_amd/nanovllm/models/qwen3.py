@@ -78,8 +78,12 @@ class ParallelLMHead(VocabParallelEmbedding):
     """bf16 (unquantized, as in the reference) vocab-parallel output projection; with TP the shards'
     logits are all-gathered so every rank can take the same argmax."""
 
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__(num_embeddings, embedding_dim)
+        self.quantized = None     # a per-row W8A16 QLinear over this rank's vocabulary shard (opt-in: quantize_lm_head)
+
     def forward(self, x):
-        logits = F.linear(x, self.weight)
+        logits = F.linear(x, self.weight) if self.quantized is None else self.quantized(x)
         if self.tp_size > 1:
             if dist.get_backend() == "gloo" and logits.is_cuda:     # test transport: gloo moves host memory
                 host = logits.cpu()

@@ -515,3 +515,16 @@ def apply_quant_from_config(model, config):
             apply_quant_torchao(model, config.linear_dtype)
     elif config.linear_dtype != torch.bfloat16:
         apply_per_row_quant(model, config.linear_dtype)
+    if getattr(config, "quantize_lm_head", False):
+        apply_lm_head_quant(model, config.linear_dtype if config.linear_dtype in _DTYPES else torch.int8)
+
+
+@torch.no_grad()
+def apply_lm_head_quant(model, dtype=torch.int8):
+    """Opt-in: the LM head (``ParallelLMHead``, nanovllm/layers/embed_head.py:45-66 in the reference, bf16
+    there) as a per-row weight-only quantized linear over this rank's vocabulary shard.  The embedding keeps
+    its bf16 weight even when the two are tied."""
+    head = model.lm_head
+    q = QLinear(dtype, head.weight.data, None, weight_only=True)
+    head.quantized = q.tile()
+    return model

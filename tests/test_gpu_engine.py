@@ -295,6 +295,29 @@ def test_engine_quantized_variants(tiny_dir, kw):
     assert rel < 0.1, float(rel)
 
 
+def test_quantized_lm_head_opt_in(tiny_dir):
+    """quantize_lm_head=True: the vocabulary projection runs through the per-row W8A16 kernel; logits stay
+    within int8 weight-quantization noise of the bf16 head (max error < 2 % of the logit range, the bar the
+    reference sets for its per-row linears is 8 %, quantization.py:549-553) and graph-mode decoding works."""
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.utils import quantization as NQ
+    kw = dict(load_format="dummy", max_model_len=512, max_num_seqs=16, quant_type="per_row_weight_only",
+              linear_dtype=torch.int8)
+    llm = LLM(tiny_dir, enforce_eager=False, quantize_lm_head=True, **kw)
+    head = llm.model_runner.model.lm_head
+    assert isinstance(head.quantized, NQ.QLinear) and head.quantized.weight_only
+    x = torch.randn(37, head.weight.shape[1], device="cuda", dtype=torch.bfloat16)
+    with torch.inference_mode():
+        got = head(x).float()
+        ref = torch.nn.functional.linear(x, head.weight).float()
+    assert got.shape == ref.shape
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 0.02
+    out = llm.generate(_prompts(), SamplingParams(max_tokens=8, ignore_eos=True))
+    assert all(len(o["token_ids"]) == 8 for o in out)
+    plain = LLM(tiny_dir, enforce_eager=False, **kw)
+    assert plain.model_runner.model.lm_head.quantized is None
+
+
 def test_weight_fake_quant_dispatch(tiny_dir):
     """weight_quant_fn takes precedence and keeps bf16 linears (model_runner.py:37-39)."""
     from nanovllm import LLM, SamplingParams
