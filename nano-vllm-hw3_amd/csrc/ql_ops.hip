@@ -248,12 +248,22 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const int tend = min(ctx, tbeg + kAttnChunk);                 // tokens [tbeg, tend) of the sequence
     const size_t hoff = (size_t)hk * 128 + seg * 8;
     constexpr int U = QL_ATTN_U;   // tokens per slot per iteration: 2*U 16-byte loads in flight per lane
+    // A chunk normally spans at most two cache blocks: their table entries are fetched once (uniform, so scalar
+    // loads), which takes a dependent table load and an integer division out of every iteration.
+    const int b0 = tbeg / block_size;
+    const int bound = (b0 + 1) * block_size;                      // first token of the chunk's second block
+    const bool two = (tbeg + kAttnChunk - 1) / block_size <= b0 + 1;
+    const int e0 = bt[b0], e1 = bt[min(b0 + 1, max_blocks - 1)];
+    const int base0 = e0 * block_size - b0 * block_size;          // cache row of token t = base + t
+    const int base1 = e1 * block_size - bound;
     for (int t0 = tbeg + wave * 4 + slot; t0 < tend; t0 += 16 * U) {
         u16x8 kk[U], vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = min(t0 + 16 * u, tend - 1);             // clamped: no divergent loads
-            const size_t off = ((size_t)bt[t / block_size] * block_size + (t % block_size)) * Hkv * 128 + hoff;
+            const size_t row = two ? (size_t)((t < bound ? base0 : base1) + t)
+                                   : (size_t)bt[t / block_size] * block_size + (t % block_size);
+            const size_t off = row * Hkv * 128 + hoff;
             // read-once stream: the non-temporal hint measured +5 % on the whole launch
             kk[u] = __builtin_nontemporal_load((const u16x8*)(k_cache + off));
             vv[u] = __builtin_nontemporal_load((const u16x8*)(v_cache + off));
