@@ -97,6 +97,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const unsigned short*
     load_tile(0);
     store_tile();
     __syncthreads();
+    // Pin the Q fragments as loaded HERE.  Otherwise their loads are sunk to the loop entry, and because the
+    // wait counter is positional every MFMA of the loop that reads them also waits for the next tile's K/V
+    // loads issued just before it: the prefetch would have to land within the first product of each tile.
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(__builtin_bit_cast(i32x4, qf[ks])));
     for (int it = 0; it < ntiles; ++it) {
         const int kt0 = it * kTileKeys;
         if (it + 1 < ntiles) load_tile(kt0 + kTileKeys);
