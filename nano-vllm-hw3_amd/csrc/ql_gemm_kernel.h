@@ -348,9 +348,11 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     };
     auto chunk_sb = [&](auto chk, int it) {
         const int kc = k0 + it * C::KB;
+        // activations first: the wait counter is positional, so staging them must not wait for the (slower,
+        // HBM) weight loads issued behind them
+        load_x(chk, kc);
 #pragma unroll
         for (int j = 0; j < D; ++j) wcur[j] = load_w1(chk, kc, j);
-        load_x(chk, kc);
         store_x(0);
         __syncthreads();
         for (int c0 = 0; c0 < CP; c0 += D) {
@@ -367,9 +369,9 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     if constexpr (DB) {
         // LDS double buffer for x, register double buffer for the weights
         if (nchunks > 0) {
+            load_x(TrueT{}, k0);                                  // (before the weights: positional wait counter)
 #pragma unroll
             for (int c = 0; c < CP; ++c) wcur[c] = load_w1(TrueT{}, k0, c);
-            load_x(TrueT{}, k0);
             store_x(0);
         }
         __syncthreads();
