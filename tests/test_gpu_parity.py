@@ -424,3 +424,37 @@ def test_full_size_properties(NQ, nk, M):
     y8 = NQ.per_row_matmul(x, qw, sw, None, torch.int8)
     yo = O.per_row_matmul(xs, bits8(qw), sw.cpu().numpy(), None, "int8")
     assert np.array_equal(bits16(y8[rows]), yo)
+
+
+# The layer shapes of the larger BASELINE configurations (Qwen3-4B: per-group g128; Qwen3-8B at TP=8): they take
+# the tile / split-K paths that the 0.6B shapes never reach (2048-k slices for K >= 8192, unsplit 64 x 128 tiles).
+QWEN3_LARGE = [(6144, 2560), (2560, 4096), (19456, 2560), (2560, 9728), (768, 4096), (4096, 512), (3072, 4096),
+               (4096, 1536)]
+
+
+@pytest.mark.parametrize("nk", QWEN3_LARGE)
+@pytest.mark.parametrize("M", [16, 130])
+def test_large_model_shapes_sampled_rows(NQ, nk, M):
+    """Per-row W8A16, per-group g128 W8A16 and int8 W8A8 at the 4B / 8B-TP8 layer shapes: sampled output rows
+    against the oracle (same bars as everywhere: float GEMMs within the bf16 + f32-accumulation allowance, the
+    int8 W8A8 GEMM bit-exact), tiled weights as the modules hold them."""
+    N, K = nk
+    g = torch.Generator(device="cuda").manual_seed(7 * N + K + M)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    rows = sorted(set([0, M // 2, M - 1]))
+    xs = bits16(x[rows])
+    qw, sw = NQ.per_row_quant(w, torch.int8)
+    qt = NQ.tile_weight(qw)
+    y = NQ.per_row_weight_only_matmul(x, qt, sw, None, torch.int8)
+    assert torch.equal(y, NQ.per_row_weight_only_matmul(x, qw, sw, None, torch.int8)), "tiled != row-major"
+    ref = O.w8a16_rowscale_matmul(xs, bits8(qw), sw.cpu().numpy(), None, "int8", return_f64=True)
+    l1 = O.abs_product_sum(xs, O._decode_q(bits8(qw), "int8") * sw.cpu().numpy()[:, None])
+    assert_gemm_close(bits16(y[rows]), ref, l1, what=f"per-row {nk} M={M}")
+    y8 = NQ.per_row_matmul(x, qt, sw, None, torch.int8)
+    assert np.array_equal(bits16(y8[rows]), O.per_row_matmul(xs, bits8(qw), sw.cpu().numpy(), None, "int8"))
+    qg, sg = NQ.per_group_quant(w, 128, torch.int8)
+    yg = NQ.per_group_matmul(x, NQ.tile_weight(qg), sg, None, 128, torch.int8)
+    refg = O.per_group_matmul(xs, bits8(qg), sg.cpu().numpy(), None, 128, "int8", return_f64=True)
+    wg = O._decode_q(bits8(qg), "int8").reshape(N, K // 128, 128) * sg.cpu().numpy()[:, :, None]
+    assert_gemm_close(bits16(yg[rows]), refg, O.abs_product_sum(xs, wg.reshape(N, K)), what=f"per-group {nk} M={M}")
