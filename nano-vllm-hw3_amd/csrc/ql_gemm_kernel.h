@@ -68,12 +68,12 @@ template <bool FP8W>
 __device__ __forceinline__ bf16x8 widen8(int d0, int d1) {
     unsigned o[4];
     if (FP8W) {
-        auto a = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false);
-        auto b = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
-        auto c = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false);
-        auto d = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
-        o[0] = pack_hi16(a[0], a[1]); o[1] = pack_hi16(b[0], b[1]);
-        o[2] = pack_hi16(c[0], c[1]); o[3] = pack_hi16(d[0], d[1]);
+        // v_cvt_scalef32_pk_bf16_fp8: two e4m3 bytes -> two packed bf16 in ONE instruction (scale 1.0, exact)
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        o[0] = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, false));
+        o[1] = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, true));
+        o[2] = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, false));
+        o[3] = __builtin_bit_cast(unsigned, (bf16x2_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, true));
     } else {
         const int dd[2] = {d0, d1};
 #pragma unroll

@@ -458,3 +458,26 @@ def test_large_model_shapes_sampled_rows(NQ, nk, M):
     refg = O.per_group_matmul(xs, bits8(qg), sg.cpu().numpy(), None, 128, "int8", return_f64=True)
     wg = O._decode_q(bits8(qg), "int8").reshape(N, K // 128, 128) * sg.cpu().numpy()[:, :, None]
     assert_gemm_close(bits16(yg[rows]), refg, O.abs_product_sum(xs, wg.reshape(N, K)), what=f"per-group {nk} M={M}")
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_fp8_weight_widening_is_exact_for_every_byte(NQ, tiled):
+    """The in-register e4m3fn -> bf16 widening of the W8A16 GEMM (one packed conversion per two weights) must
+    reproduce every finite e4m3fn value exactly: with a one-hot activation row and unit scales the output IS the
+    decoded weight.  (0x7F / 0xFF are the format's NaNs; a quantizer never emits them.)"""
+    codes = [c for c in range(256) if c not in (0x7F, 0xFF)]
+    N, K = 256, 64
+    q = torch.zeros(N, K, dtype=torch.uint8)
+    for j in range(K):
+        q[:, j] = torch.tensor([codes[(n + 7 * j) % len(codes)] for n in range(N)], dtype=torch.uint8)
+    qw = q.cuda().view(torch.float8_e4m3fn)
+    sw = torch.ones(N, device="cuda", dtype=torch.float32)
+    w = NQ.tile_weight(qw) if tiled else qw
+    for j in (0, 1, 15, 16, 31, 33, 63):
+        e = torch.zeros(3, K, device="cuda", dtype=torch.bfloat16)
+        e[1, j] = 1.0
+        y = NQ.per_row_weight_only_matmul(e, w, sw, None, torch.float8_e4m3fn)
+        expect = qw[:, j].float().to(torch.bfloat16)
+        assert torch.equal(y[1], expect), f"column {j}"
+        assert torch.equal(qw[:, j].float(), expect.float()), "e4m3fn must fit bf16 exactly"
+        assert y[0].abs().max().item() == 0 and y[2].abs().max().item() == 0
