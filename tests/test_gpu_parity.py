@@ -481,3 +481,34 @@ def test_fp8_weight_widening_is_exact_for_every_byte(NQ, tiled):
         assert torch.equal(y[1], expect), f"column {j}"
         assert torch.equal(qw[:, j].float(), expect.float()), "e4m3fn must fit bf16 exactly"
         assert y[0].abs().max().item() == 0 and y[2].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dt", ["int8", "fp8"])
+def test_one_round_tile_rule_all_variants(NQ, dt):
+    """K = 1024 with 176..256 tiles of 32 x 128 selects the eight-wave tile that keeps the whole K resident; every
+    arithmetic variant must take that path correctly (per-row W8A16, per-group, W8A8, fused SiLU)."""
+    N, K, M = 4096, 1024, 200
+    tdt = TDT[dt]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    rows = [0, 97, M - 1]
+    xs = bits16(x[rows])
+    qw, sw = NQ.per_row_quant(w, tdt)
+    y = NQ.per_row_weight_only_matmul(x, NQ.tile_weight(qw), sw, None, tdt)
+    wd = O._decode_q(bits8(qw), dt) * sw.cpu().numpy()[:, None]
+    ref = O.w8a16_rowscale_matmul(xs, bits8(qw), sw.cpu().numpy(), None, dt, return_f64=True)
+    assert_gemm_close(bits16(y[rows]), ref, O.abs_product_sum(xs, wd), what=f"per-row {dt}")
+    qg, sg = NQ.per_group_quant(w, 128, tdt)
+    yg = NQ.per_group_matmul(x, NQ.tile_weight(qg), sg, None, 128, tdt)
+    wg = (O._decode_q(bits8(qg), dt).reshape(N, K // 128, 128) * sg.cpu().numpy()[:, :, None]).reshape(N, K)
+    refg = O.per_group_matmul(xs, bits8(qg), sg.cpu().numpy(), None, 128, dt, return_f64=True)
+    assert_gemm_close(bits16(yg[rows]), refg, O.abs_product_sum(xs, wg), what=f"per-group {dt}")
+    y8 = NQ.per_row_matmul(x, NQ.tile_weight(qw), sw, None, tdt)
+    if dt == "int8":
+        assert np.array_equal(bits16(y8[rows]), O.per_row_matmul(xs, bits8(qw), sw.cpu().numpy(), None, dt))
+    # fused SiLU epilogue on the same tile: bit-identical to GEMM + SiluAndMul
+    qi, si = NQ.interleave_gate_up(qw), NQ.interleave_gate_up(sw)
+    from nanovllm import ops
+    fused = NQ.per_row_weight_only_matmul(x, NQ.tile_weight(qi), si, None, tdt, silu=True)
+    assert torch.equal(fused, ops.silu_mul(y))
