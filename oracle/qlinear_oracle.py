@@ -10,10 +10,18 @@ Parity pinning
 * per-tensor / per-group quantizers and matmuls, the fake quantizers and the TP weight loaders are
   pinned against outputs of the reference itself (``tests/golden/quant_golden.npz``, produced by
   ``tests/golden/make_golden.py`` importing the reference's torch code on CPU).
-* the per-row W8A8 path is Triton-only in the reference and cannot run without a GPU driver; its
-  restatement below follows the kernel text line by line, uses IEEE f32 division where Triton's
-  lowering is target-dependent, and is cross-checked against ``fake_per_row_quant`` golden outputs
-  on the weight side.  Bit-level parity of that half is therefore pinned only up to those checks.
+* the per-row W8A8 path is Triton-only in the reference.  Its restatement below follows the kernel
+  text line by line and is pinned against the reference's own ``@triton.jit`` kernels executed by
+  Triton's CPU interpreter (``tests/golden/triton_golden.npz``, generator
+  ``tests/golden/make_golden_triton.py``): the f32 scales, the scaled values ``x * (Q / row_max)``
+  and the GEMM's ``acc * sa * sb`` are reproduced BIT-EXACTLY up to the final narrowing cast.  The
+  interpreter narrows f32 -> bf16 by truncation and f32 -> e4m3 by a carry-less round-half-up, which
+  is not what compiled Triton does (round-to-nearest-even, as torch); the tests therefore apply the
+  interpreter's narrowing to this oracle's pre-cast values (``return_scaled`` / ``return_f32``) and
+  compare those, while the shipped semantics of the cast stay RTNE.  One call has no
+  reference-produced vector: ``libdevice.round`` of the int8 activation/weight quantizer
+  (quantization.py:41) cannot be interpreted; it is restated as C ``roundf`` and cross-checked
+  against ``fake_per_row_quant`` golden outputs on the weight side.
 
 Conventions: bf16 tensors travel as ``uint16`` bit patterns, fp8-e4m3fn and int8 as ``uint8`` /
 ``int8`` arrays, scales as ``float32``.  dtype names are the strings ``"int8"`` and ``"fp8"``.
@@ -104,13 +112,14 @@ def _decode_q(q, dtype):
 
 
 # --------------------------------------------------------------------------- quantizers
-def per_row_quant(x_bf16, dtype):
+def per_row_quant(x_bf16, dtype, return_scaled=False):
     """Dynamic per-row quantization of a bf16 matrix [T, H] (weights at init, activations at every
     forward).  Follows ``_per_row_quant_kernel`` (quantization.py:26-41) as launched by
     ``per_row_quant`` (quantization.py:147-163):
       row_max = max(max|x|, 1e-8) in f32; scale = row_max / Q; scale_inv = Q / row_max;
       y = x * scale_inv; int8: roundf(y) -> int8 ; fp8: cast(y) to e4m3fn.
-    Returns (q [T,H] int8|uint8, scale [T] f32)."""
+    Returns (q [T,H] int8|uint8, scale [T] f32); with ``return_scaled`` the f32 values y in front of
+    the narrowing cast instead of q."""
     x = bf16_to_f32(x_bf16)
     assert x.ndim == 2
     Q = np.float32(QMAX[dtype])
@@ -118,6 +127,8 @@ def per_row_quant(x_bf16, dtype):
     scale = (row_max / Q).astype(np.float32)
     scale_inv = (Q / row_max).astype(np.float32)
     y = (x * scale_inv[:, None]).astype(np.float32)
+    if return_scaled:
+        return y, scale
     if dtype == INT8:
         q = round_half_away(y).astype(np.int32).astype(np.int8)
     else:
@@ -230,7 +241,7 @@ def per_group_matmul(x_bf16, qw, sw, bias_bf16, group_size, dtype, return_f64=Fa
     return _bf16_add_bias(f32_to_bf16(acc.astype(np.float32)), bias_bf16)
 
 
-def w8a8_gemm(qx, sx, qw, sw, bias_bf16, dtype, return_acc=False):
+def w8a8_gemm(qx, sx, qw, sw, bias_bf16, dtype, return_acc=False, return_f32=False):
     """``_per_row_post_process_mm`` (quantization.py:93-144): acc = sum_k qx[m,k]*qw[n,k] (exact
     int32 for int8; f32 with unspecified order for fp8 - evaluated exactly in f64 here), then in
     f32 ``c = acc * sa[m] * sb[n]`` in that order, ``+ bias[n]`` in f32, one cast to bf16.
@@ -253,6 +264,8 @@ def w8a8_gemm(qx, sx, qw, sw, bias_bf16, dtype, return_acc=False):
     c = (c * np.asarray(sw, np.float32)[None, :]).astype(np.float32)
     if bias_bf16 is not None:
         c = (c + bf16_to_f32(bias_bf16)[None, :]).astype(np.float32)
+    if return_f32:                  # the f32 value in front of the cast to the output dtype (:144)
+        return c
     return f32_to_bf16(c)
 
 

@@ -17,3 +17,11 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "quant_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def triton_golden():
+    """Outputs of the reference's @triton.jit kernels under Triton's CPU interpreter
+    (tests/golden/make_golden_triton.py)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "triton_golden.npz"))

@@ -26,6 +26,20 @@ def NQ():
     return NQ
 
 
+def fp8_w8a8_exact(xb, qw, sw, bias=None):
+    """Exactly evaluated fp8 W8A8 forward (dynamic per-row activation quantization by the oracle, f64
+    contraction, f64 scales) and the L1 bound of its f32 accumulation: the (ref, l1) pair assert_gemm_close takes."""
+    qx, sx = O.per_row_quant(xb, "fp8")
+    acc = O.w8a8_gemm(qx, sx, qw, sw, None, "fp8", return_acc=True)
+    sc = sx[:, None].astype(np.float64) * np.asarray(sw, np.float64)[None, :]
+    ref = acc * sc
+    l1 = (np.abs(O.fp8_to_f32(qx)).astype(np.float64) @ np.abs(O.fp8_to_f32(qw)).astype(np.float64).T) * sc
+    if bias is not None:
+        ref = ref + O.bf16_to_f32(bias)[None, :]
+        l1 = l1 + np.abs(O.bf16_to_f32(bias))[None, :]
+    return ref, l1
+
+
 # ----------------------------------------------------------------------------- quantizers
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("dt", DTYPES)
@@ -145,16 +159,50 @@ def test_w8a8_vs_oracle(NQ, dt, mnk):
         if dt == "int8":
             assert np.array_equal(bits16(y), yo), "int8 W8A8 must be bit-exact (exact int32 accumulation)"
         else:
-            qx, sx = O.per_row_quant(xb, dt)
-            acc = O.w8a8_gemm(qx, sx, qwo, swo, None, dt, return_acc=True)
-            ref = acc * sx[:, None].astype(np.float64) * swo[None, :].astype(np.float64)
-            l1 = (np.abs(O.fp8_to_f32(qx)).astype(np.float64) @ np.abs(O.fp8_to_f32(qwo)).astype(np.float64).T) \
-                * sx[:, None] * swo[None, :]
-            if bias is not None:
-                ref = ref + O.bf16_to_f32(bias)[None, :]
-                l1 = l1 + np.abs(O.bf16_to_f32(bias))[None, :]
-            assert_gemm_close(bits16(y), ref, l1, what="fp8 W8A8")
-            assert (bits16(y) == yo).mean() > 0.98
+            ref, l1 = fp8_w8a8_exact(xb, qwo, swo, bias)
+            assert_gemm_close(bits16(y), ref, l1, what="fp8 W8A8")     # every element
+
+
+TRITON_CASES = ["m1_n64_k128", "m3_n64_k256", "m16_n48_k512", "m130_n64_k256", "m5_n8_k3072", "m130_n200_k384",
+                "m7_n130_k128"]
+
+
+@pytest.mark.parametrize("case", TRITON_CASES)
+def test_per_row_path_vs_reference_triton_vectors(NQ, triton_golden, case):
+    """The HIP per-row path against outputs of the reference's own Triton kernels (CPU interpreter).  The
+    interpreter's narrowing casts differ from compiled Triton's round-to-nearest-even (tests/util.py), so:
+    scales bit-exact; fp8 codes bit-exact wherever the interpreter's cast of the same f32 value agrees with RTNE;
+    the int8 GEMM equal to the truncated vector or its successor in magnitude (= RTNE of the same f32 value, which
+    the oracle test pins bit-exactly); the fp8 GEMM within one bf16 ulp + the f32-accumulation allowance."""
+    from tests.util import interp_f32_to_e4m3
+    g = triton_golden
+    fp8 = torch.float8_e4m3fn
+    for side in ("w", "x"):
+        q, s = NQ.per_row_quant(bf16_t(g[f"{case}/{side}"]), fp8)
+        assert np.array_equal(s.cpu().numpy(), g[f"{case}/fp8/s{side}"])
+        yo, _ = O.per_row_quant(g[f"{case}/{side}"], "fp8", return_scaled=True)
+        ib, valid = interp_f32_to_e4m3(yo)
+        agree = valid & (ib == O.f32_to_fp8(yo))
+        assert agree.mean() > 0.9
+        assert np.array_equal(bits8(q)[agree], g[f"{case}/fp8/q{side}"][agree])
+    # int8 GEMM on the stored operands
+    qx, sx, qw, sw = (g[f"{case}/int8/{k}"] for k in ("qx", "sx", "qw", "sw"))
+    y = NQ.w8a8_matmul(q_t(qx, "int8"), torch.from_numpy(sx).cuda(), q_t(qw, "int8"), torch.from_numpy(sw).cuda(),
+                       None, torch.int8)
+    d = bits16(y).astype(np.int32) - g[f"{case}/int8/y"].astype(np.int32)
+    assert ((d == 0) | (d == 1)).all()
+    assert np.array_equal(bits16(y), O.w8a8_gemm(qx, sx, qw, sw, None, "int8"))
+    # fp8 GEMM on the stored operands (the interpreter's codes are valid e4m3 bytes like any other)
+    qx, sx, qw, sw = (g[f"{case}/fp8/{k}"] for k in ("qx", "sx", "qw", "sw"))
+    y = NQ.w8a8_matmul(q_t(qx, "fp8"), torch.from_numpy(sx).cuda(), q_t(qw, "fp8"), torch.from_numpy(sw).cuda(),
+                       None, fp8)
+    sc = sx[:, None].astype(np.float64) * sw[None, :].astype(np.float64)
+    ref = O.w8a8_gemm(qx, sx, qw, sw, None, "fp8", return_acc=True) * sc
+    l1 = (np.abs(O.fp8_to_f32(qx)).astype(np.float64) @ np.abs(O.fp8_to_f32(qw)).astype(np.float64).T) * sc
+    assert_gemm_close(bits16(y), ref, l1, what="fp8 W8A8 vs exact")
+    gold = O.bf16_to_f32(g[f"{case}/fp8/y"]).astype(np.float64)
+    got = O.bf16_to_f32(bits16(y)).astype(np.float64)
+    assert (np.abs(got - gold) <= 2.0 ** -7 * np.abs(ref) + 2.0 ** -17 * l1 + 1e-30).all()
 
 
 def test_w8a8_reference_selftest_tolerance(NQ):
@@ -204,7 +252,8 @@ def test_every_tile_configuration(NQ, tile, split):
             if dt == "int8":
                 assert np.array_equal(bits16(y8), yo), f"w8a8 int8 {tile} split {split}"
             else:
-                assert (bits16(y8) == yo).mean() > 0.98
+                ref8, l18 = fp8_w8a8_exact(xb, qo, so)
+                assert_gemm_close(bits16(y8), ref8, l18, what=f"w8a8 fp8 {tile} split {split}")   # every element
             if tile[0] <= 4:
                 g = 32 if dt == "int8" else 64
                 qg, sg = O.per_group_quant(wb[:, :1152], g, dt)
@@ -424,6 +473,18 @@ def test_full_size_properties(NQ, nk, M):
     y8 = NQ.per_row_matmul(x, qw, sw, None, torch.int8)
     yo = O.per_row_matmul(xs, bits8(qw), sw.cpu().numpy(), None, "int8")
     assert np.array_equal(bits16(y8[rows]), yo)
+    # FP8 weight + activation (fp8 MFMA, f32 accumulation) and fp8 per-group g128 at the same shapes
+    fp8 = torch.float8_e4m3fn
+    qf, sf = NQ.per_row_quant(w, fp8)
+    yf = NQ.per_row_matmul(x, NQ.tile_weight(qf), sf, None, fp8)
+    assert torch.equal(yf, NQ.per_row_matmul(x, NQ.tile_weight(qf), sf, None, fp8)), "not deterministic"
+    reff, l1f = fp8_w8a8_exact(xs, bits8(qf), sf.cpu().numpy())
+    assert_gemm_close(bits16(yf[rows]), reff, l1f, what=f"fp8 W8A8 {nk} M={M}")
+    qg, sg = NQ.per_group_quant(w, 128, fp8)
+    yg = NQ.per_group_matmul(x, NQ.tile_weight(qg), sg, None, 128, fp8)
+    wg = (O._decode_q(bits8(qg), "fp8").reshape(N, K // 128, 128) * sg.cpu().numpy()[:, :, None]).reshape(N, K)
+    refg = O.per_group_matmul(xs, bits8(qg), sg.cpu().numpy(), None, 128, "fp8", return_f64=True)
+    assert_gemm_close(bits16(yg[rows]), refg, O.abs_product_sum(xs, wg), what=f"fp8 per-group {nk} M={M}")
 
 
 # The layer shapes of the larger BASELINE configurations (Qwen3-4B: per-group g128; Qwen3-8B at TP=8): they take
@@ -458,6 +519,17 @@ def test_large_model_shapes_sampled_rows(NQ, nk, M):
     refg = O.per_group_matmul(xs, bits8(qg), sg.cpu().numpy(), None, 128, "int8", return_f64=True)
     wg = O._decode_q(bits8(qg), "int8").reshape(N, K // 128, 128) * sg.cpu().numpy()[:, :, None]
     assert_gemm_close(bits16(yg[rows]), refg, O.abs_product_sum(xs, wg.reshape(N, K)), what=f"per-group {nk} M={M}")
+    # the same shapes in fp8: W8A8 on fp8 MFMA and per-group g128 weight-only
+    fp8 = torch.float8_e4m3fn
+    qf, sf = NQ.per_row_quant(w, fp8)
+    yf = NQ.per_row_matmul(x, NQ.tile_weight(qf), sf, None, fp8)
+    reff, l1f = fp8_w8a8_exact(xs, bits8(qf), sf.cpu().numpy())
+    assert_gemm_close(bits16(yf[rows]), reff, l1f, what=f"fp8 W8A8 {nk} M={M}")
+    qg, sg = NQ.per_group_quant(w, 128, fp8)
+    yg = NQ.per_group_matmul(x, NQ.tile_weight(qg), sg, None, 128, fp8)
+    wg = (O._decode_q(bits8(qg), "fp8").reshape(N, K // 128, 128) * sg.cpu().numpy()[:, :, None]).reshape(N, K)
+    refg = O.per_group_matmul(xs, bits8(qg), sg.cpu().numpy(), None, 128, "fp8", return_f64=True)
+    assert_gemm_close(bits16(yg[rows]), refg, O.abs_product_sum(xs, wg), what=f"fp8 per-group {nk} M={M}")
 
 
 @pytest.mark.parametrize("tiled", [False, True])
@@ -507,6 +579,9 @@ def test_one_round_tile_rule_all_variants(NQ, dt):
     y8 = NQ.per_row_matmul(x, NQ.tile_weight(qw), sw, None, tdt)
     if dt == "int8":
         assert np.array_equal(bits16(y8[rows]), O.per_row_matmul(xs, bits8(qw), sw.cpu().numpy(), None, dt))
+    else:
+        ref8, l18 = fp8_w8a8_exact(xs, bits8(qw), sw.cpu().numpy())
+        assert_gemm_close(bits16(y8[rows]), ref8, l18, what="fp8 W8A8")
     # fused SiLU epilogue on the same tile: bit-identical to GEMM + SiluAndMul
     qi, si = NQ.interleave_gate_up(qw), NQ.interleave_gate_up(sw)
     from nanovllm import ops

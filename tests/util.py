@@ -45,3 +45,29 @@ def assert_gemm_close(y_bits, ref64, l1, double_round=False, what=""):
         raise AssertionError(
             f"{what}: {bad.sum()}/{bad.size} outside tolerance; first at {tuple(i)}: got {got[tuple(i)]!r} "
             f"ref {ref64[tuple(i)]!r} tol {tol[tuple(i)]!r}")
+
+
+# ---- the narrowing casts of Triton's CPU interpreter (triton/runtime/interpreter.py, _convert_float) ----
+# tests/golden/triton_golden.npz was produced by the reference's kernels under TRITON_INTERPRET=1, whose
+# f32 -> bf16 cast truncates and whose f32 -> e4m3 cast adds the first dropped mantissa bit WITHOUT carrying
+# into the exponent (the sum is OR-ed into place).  Compiled Triton rounds to nearest even, so these are
+# properties of the vector generator, restated here only to compare pre-cast values bit for bit.
+def interp_f32_to_bf16(f):
+    return (np.ascontiguousarray(f, dtype=np.float32).view(np.uint32) >> np.uint32(16)).astype(np.uint16)
+
+
+def interp_f32_to_e4m3(f):
+    """Returns (bits, valid): ``valid`` marks the elements whose magnitude is an e4m3 NORMAL number or zero;
+    the interpreter's handling of the subnormal range is left out (callers skip those few elements)."""
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    u = f.view(np.uint32)
+    sign = (u >> np.uint32(31)).astype(np.uint32)
+    exp = ((u >> np.uint32(23)) & np.uint32(0xFF)).astype(np.int64)
+    sig = u & np.uint32(0x7FFFFF)
+    e_out = np.clip(exp - 127 + 7, 0, 15).astype(np.uint32)
+    m_out = ((sig >> np.uint32(20)) & np.uint32(7)) + ((sig & np.uint32(1 << 19)) > 0)
+    bits = (sign << np.uint32(7)) | (e_out << np.uint32(3)) | m_out.astype(np.uint32)
+    zero = (u & np.uint32(0x7FFFFFFF)) == 0
+    bits = np.where(zero, sign << np.uint32(7), bits)
+    valid = zero | (exp - 127 + 7 >= 1)
+    return bits.astype(np.uint8), valid
