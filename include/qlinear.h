@@ -58,8 +58,8 @@ int ql_quant_per_tensor(int dtype, const void* w_bf16, int64_t N, int64_t K, voi
                         void* workspace, void* stream);
 
 /* per_group_quant (:194-234).  scales[N, K/group] f32 = max(amax_group,1e-8)/Q; q = x/scale with
- * round-half-even + clamp (int8) or RTNE cast (fp8).  Requires group % 8 == 0, group <= 512,
- * 512 % group == 0 and K % group == 0. */
+ * round-half-even + clamp (int8) or RTNE cast (fp8).  Requires group % 8 == 0 and K % group == 0 (the
+ * reference: any divisor of K, :205); the GEMM below needs group % 32 == 0. */
 int ql_quant_per_group(int dtype, const void* w_bf16, int64_t N, int64_t K, int group, void* q,
                        float* scales, void* stream);
 
@@ -86,6 +86,10 @@ int ql_tile_weight(const void* qw, void* out, int64_t N, int64_t K, void* stream
  * first 64 KiB hold the counters, which every call leaves at zero again.  Calls that share a
  * workspace must be ordered on one stream. */
 size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity);
+/* The largest ql_gemm_workspace_bytes(M, N, K, granularity) over 1 <= M <= max_M: what to reserve once for a
+ * weight whose calls may bring any number of rows up to max_M (e.g. the scheduler's token budget) when the
+ * workspace must never be re-allocated afterwards (pointers baked into captured hipGraphs). */
+size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int granularity);
 
 /* Weight-only forward: y[M,N] bf16 = x[M,K] bf16 . dequant(qw[N,K])^T (+ bias[N] bf16).
  *   QL_PER_ROW    y = bf16( (sum_k x*q) * sw[n] + bias )                 - the W8A16 counterpart of
@@ -95,7 +99,7 @@ size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity)
  *   QL_PER_GROUP  y = bf16( bf16(sum_g sw[n,g] * sum_{k in g} x*q) + bias ) - per_group_matmul (:265-307)
  * int8/fp8 weights are widened to bf16 in registers (exact) and contracted on bf16 MFMA with f32
  * accumulation; nothing is dequantised to memory.  Requires K % 32 == 0; per-group additionally
- * (group % 128 == 0) or (128 % group == 0 and group >= 32), and K % group == 0. */
+ * group % 32 == 0 and K % group == 0 (a group's partial sum is folded with its scale at 32-k steps). */
 int ql_gemm_w8a16(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
                   const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
                   void* workspace, size_t workspace_bytes, void* stream);

@@ -9,9 +9,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nanovllm", "_lib")
 LIB = os.path.join(OUT_DIR, "libqlinear.so")
-SOURCES = ["ql_quant.hip", "ql_gemm.hip", "ql_ops.hip", "ql_attn_prefill.hip", "ql_gemm_inst_bf16_i8_row.hip", "ql_gemm_inst_bf16_i8_group.hip",
-           "ql_gemm_inst_bf16_fp8_row.hip", "ql_gemm_inst_bf16_fp8_group.hip", "ql_gemm_inst_i8_i8.hip",
-           "ql_gemm_inst_fp8_fp8.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 
 
@@ -36,7 +33,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "qlinear.h"))
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))      # every translation unit of csrc/
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

@@ -127,7 +127,8 @@ static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_byte
     // XCD-aware tile order for grids of many tiles per XCD (prefill): the XCD grouping along N that keeps an
     // XCD's weight slice within about half of its 4 MiB L2
     p.swz_gn = 0;
-    if (pl.split == 1 && pl.grid.x * pl.grid.y >= 512 && !getenv("QL_NO_XCD_SWIZZLE")) {
+    static const bool no_swizzle = getenv("QL_NO_XCD_SWIZZLE") != nullptr;    // read once, not per launch
+    if (pl.split == 1 && pl.grid.x * pl.grid.y >= 512 && !no_swizzle) {
         const uint64_t wbytes = (uint64_t)p.N * p.K;
         for (int gn = 1; gn <= 8; gn *= 2) {
             if (pl.grid.x % gn || pl.grid.y % (8 / gn)) continue;
@@ -149,6 +150,20 @@ extern "C" {
 size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
     return plan_workspace(make_plan(M, N, K, granularity == QL_PER_GROUP));
+}
+
+size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int granularity) {
+    if (max_M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
+    // every threshold of the tile / split heuristics sits on a multiple of 32 rows and the tiles are multiples
+    // of 32 rows tall, so the plan is the same for all M of one 32-row block: its last M stands for the block
+    size_t need = 0;
+    for (int64_t m = 32;; m += 32) {
+        const int64_t mm = m < max_M ? m : max_M;
+        const size_t b = plan_workspace(make_plan(mm, N, K, granularity == QL_PER_GROUP));
+        if (b > need) need = b;
+        if (mm == max_M) break;
+    }
+    return need;
 }
 
 int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
@@ -180,7 +195,7 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     if (silu && N % 64) { set_error("%s: N=%lld must be a multiple of 64 (32-row gate/up strips)", fn, (long long)N); return QL_ESHAPE; }
     const bool grp = granularity == QL_PER_GROUP;
     if (grp) {
-        const bool ok = group >= 32 && K % group == 0 && ((group % 128) == 0 || (128 % group) == 0);
+        const bool ok = group >= 32 && group % 32 == 0 && K % group == 0;   // the kernels fold a group's sum at 32-k steps
         if (!ok) { set_error("%s: group=%d unsupported for K=%lld", fn, group, (long long)K); return QL_ESHAPE; }
     }
     if (M == 0) return QL_OK;
@@ -222,6 +237,28 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
+
+}  // extern "C"
+
+namespace ql {
+// for the library's other translation units: the weight-only GEMM on a workspace of the caller's choice, and
+// what a problem needs of it (total bytes; *ticket_bytes = the head of the workspace that must be zero)
+int w8a16_dispatch(const char* fn, int wdtype, int granularity, const void* x, const void* qw, const float* sw,
+                   const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    return gemm_w8a16(fn, false, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, workspace, workspace_bytes, stream);
+}
+size_t w8a16_workspace_need(int64_t M, int64_t N, int64_t K, int granularity, size_t* ticket_bytes) {
+    *ticket_bytes = 0;
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
+    const Plan pl = make_plan(M, N, K, granularity == QL_PER_GROUP);
+    const size_t need = plan_workspace(pl);
+    if (need) *ticket_bytes = ((size_t)pl.grid.x * pl.grid.y * 4 + 15) / 16 * 16;
+    return need;
+}
+}  // namespace ql
+
+extern "C" {
 
 int ql_gemm_w8a16(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
                   void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace, size_t workspace_bytes,

@@ -298,11 +298,11 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             }
         }
         if (GROUP) {
-            // flush at every group end, and at the end of a wave chunk (the next chunk of this
-            // wave may belong to another group, or continue this one: both are handled by
-            // scaling what has been summed so far with the current group's scale)
-            const int gq = (p.group < C::KW) ? p.group : C::KW;
-            if (((kb + 32) % gq) == 0 || kb + 32 >= kend) flush_group(kb);
+            // flush at every true group end, and at the end of a wave chunk (the next chunk of this wave
+            // starts at another k: it may belong to another group or continue this one, and both are handled
+            // by scaling what has been summed so far with the current group's scale).  Any group size that is
+            // a multiple of the 32-k step is exact this way, whatever its relation to the chunk length.
+            if (((kb + 32) % p.group) == 0 || c == CP - 1 || kb + 32 >= kend) flush_group(kb);
         }
     };
 
@@ -578,6 +578,12 @@ kern_t pick_kernel_impl(int mt, int wn, int wk, int cp) {
 #undef QL_PICK
     return nullptr;
 }
+
+// host side, defined in ql_gemm.hip (see there)
+int w8a16_dispatch(const char* fn, int wdtype, int granularity, const void* x, const void* qw, const float* sw,
+                   const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace,
+                   size_t workspace_bytes, void* stream);
+size_t w8a16_workspace_need(int64_t M, int64_t N, int64_t K, int granularity, size_t* ticket_bytes);
 
 kern_t pick_bf16_i8_row(int, int, int, int);
 kern_t pick_bf16_i8_group(int, int, int, int);

@@ -189,7 +189,44 @@ __global__ __launch_bounds__(256) void fake_per_tensor_kernel(const unsigned sho
         fake8<DT>(*(const u16x8*)(x + e), amax, out + e);
 }
 
-static bool group_ok(int g) { return g >= 8 && g <= 512 && (g % 8) == 0 && (512 % g) == 0; }
+// any other group size that is a multiple of 8 (96, 384, 1024, ...): one wave per group, its lanes stride over
+// the group's 16-byte pieces; same arithmetic as the kernels above.  FAKE: quantize-dequantize to bf16.
+template <int DT, bool FAKE>
+__global__ __launch_bounds__(256) void per_group_wave_kernel(const unsigned short* __restrict__ x,
+                                                             unsigned char* __restrict__ q, float* __restrict__ scales,
+                                                             unsigned short* __restrict__ out, int64_t ngroups, int group) {
+    const int lane = threadIdx.x & 63;
+    const int pieces = group >> 3;
+    for (int64_t gi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gi < ngroups; gi += (int64_t)gridDim.x * 4) {
+        const unsigned short* xg = x + gi * group;
+        float m = 0.f;
+        for (int c = lane; c < pieces; c += 64) m = fmaxf(m, absmax8(*(const u16x8*)(xg + c * 8)));
+        m = wave_max(m);
+        if (FAKE) {
+            m = fmaxf(m, round_to_bf16(1e-8f));
+            for (int c = lane; c < pieces; c += 64) fake8<DT>(*(const u16x8*)(xg + c * 8), m, out + gi * group + c * 8);
+        } else {
+            const float sc = fmaxf(m, 1e-8f) / QMax<DT>::v;
+            if (lane == 0) scales[gi] = sc;
+            for (int c = lane; c < pieces; c += 64) {
+                const u16x8 v = *(const u16x8*)(xg + c * 8);
+                unsigned long long o8 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = bf16_bits_to_f32(v[j]) / sc;
+                    unsigned b;
+                    if (DT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)fminf(fmaxf(rintf(y), -128.f), 127.f);
+                    else b = f32_to_e4m3fn(y);
+                    o8 |= (unsigned long long)b << (8 * j);
+                }
+                *(unsigned long long*)(q + gi * group + c * 8) = o8;
+            }
+        }
+    }
+}
+
+static bool group_pow2(int g) { return g >= 8 && g <= 512 && (g % 8) == 0 && (512 % g) == 0; }   // shuffle kernels
+static bool group_ok(int g) { return g >= 8 && (g % 8) == 0; }
 static int stream_grid(int64_t total) {
     int64_t b = (total / 8 + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -245,12 +282,24 @@ int ql_quant_per_group(int dtype, const void* w, int64_t N, int64_t K, int group
         return QL_EINVAL;
     }
     if (!group_ok(group) || K % group) {
-        set_error("ql_quant_per_group: K=%lld, group=%d unsupported (need group|512, group%%8==0, K%%group==0)",
+        set_error("ql_quant_per_group: K=%lld, group=%d unsupported (need group%%8==0 and K%%group==0)",
                   (long long)K, group);
         return QL_ESHAPE;
     }
     const int64_t total = N * K;
     if (total == 0) return QL_OK;
+    if (!group_pow2(group)) {
+        const int64_t ngroups = total / group;
+        dim3 grid((unsigned)((ngroups + 3) / 4 > 8192 ? 8192 : (ngroups + 3) / 4)), block(256);
+        if (dtype == QL_INT8)
+            hipLaunchKernelGGL((per_group_wave_kernel<QL_INT8, false>), grid, block, 0, as_stream(stream),
+                               (const unsigned short*)w, (unsigned char*)q, scales, (unsigned short*)nullptr, ngroups, group);
+        else
+            hipLaunchKernelGGL((per_group_wave_kernel<QL_FP8, false>), grid, block, 0, as_stream(stream),
+                               (const unsigned short*)w, (unsigned char*)q, scales, (unsigned short*)nullptr, ngroups, group);
+        QL_CHECK_LAUNCH("ql_quant_per_group");
+        return QL_OK;
+    }
     const int64_t blocks = (total / 8 + 255) / 256;
     if (blocks > 0x7FFFFFFF) { set_error("ql_quant_per_group: tensor too large"); return QL_ESHAPE; }
     dim3 grid((unsigned)blocks), block(256);
@@ -307,7 +356,13 @@ int ql_fake_quant(int dtype, int granularity, const void* w, int64_t N, int64_t 
         const int64_t blocks = (total / 8 + 255) / 256;
         if (blocks > 0x7FFFFFFF) { set_error("ql_fake_quant: tensor too large"); return QL_ESHAPE; }
         dim3 grid((unsigned)blocks), block(256);
-        if (dtype == QL_INT8) hipLaunchKernelGGL(fake_per_group_kernel<QL_INT8>, grid, block, 0, s, x, o, total, group);
+        if (!group_pow2(group)) {
+            const int64_t ngroups = total / group;
+            dim3 wgrid((unsigned)((ngroups + 3) / 4 > 8192 ? 8192 : (ngroups + 3) / 4));
+            if (dtype == QL_INT8) hipLaunchKernelGGL((per_group_wave_kernel<QL_INT8, true>), wgrid, block, 0, s, x, (unsigned char*)nullptr, (float*)nullptr, o, ngroups, group);
+            else hipLaunchKernelGGL((per_group_wave_kernel<QL_FP8, true>), wgrid, block, 0, s, x, (unsigned char*)nullptr, (float*)nullptr, o, ngroups, group);
+        }
+        else if (dtype == QL_INT8) hipLaunchKernelGGL(fake_per_group_kernel<QL_INT8>, grid, block, 0, s, x, o, total, group);
         else hipLaunchKernelGGL(fake_per_group_kernel<QL_FP8>, grid, block, 0, s, x, o, total, group);
     } else if (granularity == QL_PER_TENSOR) {
         if (!workspace) { set_error("ql_fake_quant: per-tensor needs a workspace"); return QL_EINVAL; }

@@ -27,6 +27,7 @@ SIGNATURES = {
     "ql_fake_quant": (_c_int, [_c_int, _c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),
     "ql_tile_weight": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_gemm_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_int]),
+    "ql_gemm_workspace_max_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_int]),
     "ql_gemm_w8a16": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                _c_int, _c_vp, _c_sz, _c_vp]),
     "ql_gemm_w8a8": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
@@ -102,14 +103,29 @@ def require_cuda(t, dtype, name):
 
 class _Workspace:
     """One growable scratch buffer per device for split-K slabs.  It is sized outside graph capture
-    (reserve()); during capture a too-small workspace is an error instead of a hidden allocation."""
+    (reserve()); during capture a too-small workspace is an error instead of a hidden allocation.
+    Captured hipGraphs hold the buffer by ADDRESS: once pin() has been called for a device, a buffer that is
+    outgrown is kept alive for the rest of the process (the graphs keep using it, correctly: it fits every
+    shape they captured) and only later eager calls move to the larger one."""
 
     def __init__(self):
         self.buf = {}
+        self.pinned = {}      # device -> buffers captured graphs may still address
+
+    @staticmethod
+    def _key(device):
+        device = torch.device(device)
+        return device.index if device.index is not None else torch.cuda.current_device()
+
+    def pin(self, device):
+        key = self._key(device)
+        cur = self.buf.get(key)
+        if cur is not None and not any(cur is b for b in self.pinned.setdefault(key, [])):
+            self.pinned[key].append(cur)
 
     def reserve(self, device, nbytes):
         device = torch.device(device)
-        key = device.index if device.index is not None else torch.cuda.current_device()
+        key = self._key(device)
         cur = self.buf.get(key)
         if cur is None or cur.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():

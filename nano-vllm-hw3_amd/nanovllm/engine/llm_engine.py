@@ -64,7 +64,7 @@ class LLMEngine:
         is in every decode step, and there are enough free KV blocks that nothing can be preempted."""
         sch = self.scheduler
         return (self.pipeline_decode and not sch.waiting and len(sch.running) <= sch.max_num_seqs and
-                len(sch.block_manager.free) >= len(sch.running))
+                len(sch.block_manager.free) >= len(sch.running) and self.model_runner.can_stage(sch.running))
 
     def is_finished(self):
         return self.scheduler.is_finished()

@@ -49,16 +49,12 @@ class ModelRunner:
             self._init_decode_staging(min(config.max_num_seqs, 512),
                                       (config.max_model_len + self.block_size - 1) // self.block_size)
             if not self.enforce_eager:
-                try:
-                    self.capture_graphs()
-                except Exception as ex:   # e.g. a collective that cannot be captured on this RCCL build
-                    if self.world_size == 1:
-                        raise
-                    import warnings
-                    warnings.warn(f"hipGraph capture failed under tensor parallelism ({ex!r}); decoding eagerly")
-                    self.graphs = {}
-                    self.enforce_eager = True
-                    torch.cuda.synchronize()
+                # no eager fallback: a capture that fails (e.g. a collective this RCCL build cannot capture)
+                # raises, and the caller decides (enforce_eager=True)
+                self.capture_graphs()
+                from nanovllm import _qlinear
+                _qlinear.workspace.pin(self.device)        # the graphs address these buffers: never freed
+                _qlinear.attn_workspace.pin(self.device)
         finally:
             torch.set_default_device("cpu")
             torch.set_default_dtype(default_dtype)
@@ -77,9 +73,12 @@ class ModelRunner:
         return sorted(shapes)
 
     def _reserve_gemm_workspace(self):
+        # over every row count a call can bring: decode buckets AND eager prefill batches.  The decode hipGraphs
+        # bake the buffer's address in; sized here it is never outgrown by this engine's own calls, and
+        # _Workspace.pin keeps it alive should another engine of the process need a larger one.
         shapes = self._linear_shapes()
         if shapes:
-            reserve_workspace(min(self.config.max_num_seqs, 512), shapes, self.device)
+            reserve_workspace(max(self.config.max_num_batched_tokens, self.config.max_num_seqs), shapes, self.device)
 
     def allocate_kv_cache(self):
         cfg, hf = self.config, self.config.hf_config
@@ -161,6 +160,11 @@ class ModelRunner:
         self._tok_host = [torch.zeros(max(max_bs, self.config.max_num_seqs), dtype=torch.int64, device="cpu",
                                       pin_memory=True) for _ in range(2)]
         self._tok_turn = 0
+
+    def can_stage(self, seqs):
+        """True when a decode step over ``seqs`` fits the staging buffers (what pipelined decode needs)."""
+        return (len(seqs) <= self._stage_max_bs and
+                all(len(s.block_table) + 1 <= self._stage_max_blocks for s in seqs))
 
     def prepare_decode(self, seqs, perm=None):
         """Fills a pinned mirror and issues the one copy; returns device views of the first len(seqs)

@@ -228,16 +228,15 @@ def interleave_gate_up(t: torch.Tensor):
 
 
 def reserve_workspace(max_tokens: int, shapes, device=None):
-    """Size the split-K scratch for every [N, K] in ``shapes`` and every graph-captured batch up to
-    ``max_tokens`` (call before hipGraph capture: nothing may allocate inside a capture)."""
+    """Size the split-K scratch for every [N, K] in ``shapes`` and EVERY row count up to ``max_tokens`` (pass the
+    largest batch any call can bring, prefill included; call before hipGraph capture: nothing may allocate
+    inside a capture and the captured launches keep the buffer's address)."""
     lib = Q.load()
     device = device if device is not None else torch.cuda.current_device()
     need = 0
-    ms = sorted(set([1, 2, 4, 8] + list(range(16, max(max_tokens, 16) + 1, 16)) + [max_tokens]))
     for (N, K) in shapes:
-        for M in ms:
-            for gran in (Q.QL_PER_ROW, Q.QL_PER_GROUP):
-                need = max(need, lib.ql_gemm_workspace_bytes(M, N, K, gran))
+        for gran in (Q.QL_PER_ROW, Q.QL_PER_GROUP):
+            need = max(need, lib.ql_gemm_workspace_max_bytes(max(int(max_tokens), 1), N, K, gran))
     Q.workspace.reserve(device, need)
     return need
 
@@ -270,7 +269,9 @@ class _QBase(torch.nn.Module):
         if self.sw.dim() >= 1 and self.sw.shape[0] == self.qw.shape[0]:      # per-row [N] / per-group [N, K/g]
             self.sw = interleave_gate_up(self.sw)
         if self.bias is not None:
-            self.bias = interleave_gate_up(self.bias.data)
+            b = interleave_gate_up(self.bias.data)
+            # (the bias of a converted linear is a registered Parameter: a plain tensor cannot replace it)
+            self.bias = torch.nn.Parameter(b, requires_grad=False) if isinstance(self.bias, torch.nn.Parameter) else b
         self.silu_fused = True
         return self
 

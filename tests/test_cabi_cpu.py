@@ -47,7 +47,9 @@ def test_argument_validation_needs_no_gpu():
     assert b"bad argument" in lib.ql_last_error()
     assert lib.ql_gemm_w8a16(0, 0, one, one, one, None, one, 4, 64, 100, 0, None, 0, None) == -2
     assert b"multiple of 32" in lib.ql_last_error()
-    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 256, 96, None, 0, None) == -2
+    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 256, 96, None, 0, None) == -2    # K % group
+    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 240, 48, None, 0, None) == -2    # K % 32
+    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 192, 48, None, 0, None) == -2    # group % 32
     assert lib.ql_quant_per_group(0, one, 4, 256, 96, one, one, None) == -2
     assert lib.ql_quant_per_row(0, one, 4, 100, one, one, None) == -2
     assert lib.ql_gemm_w8a8(0, one, one, one, None, None, one, 4, 64, 128, None, 0, None) == -1
@@ -58,6 +60,21 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ql_gemm_workspace_bytes(16, 64, 2048, 0) == 65536 + 2 * 4 * (1 * 1 * 16 * 64 * 4)
     assert lib.ql_gemm_force_config(0, 0, 0, 0, 0) == 0
     assert lib.ql_gemm_workspace_bytes(4096, 4096, 1024, 0) == 0
+
+
+def test_workspace_max_covers_every_row_count():
+    """ql_gemm_workspace_max_bytes(max_M) is the maximum of ql_gemm_workspace_bytes over 1..max_M (brute force), so
+    one reservation covers decode buckets and eager prefill batches alike; includes the Qwen3-4B down_proj shape
+    whose M = 600 call needs more than any M <= 512."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    for (N, K) in [(1024, 3072), (2560, 9728), (2048, 6144), (4096, 1024), (64, 256)]:
+        for gran in (0, 2):
+            brute = max(lib.ql_gemm_workspace_bytes(m, N, K, gran) for m in range(1, 2101))
+            assert lib.ql_gemm_workspace_max_bytes(2100, N, K, gran) == brute
+    assert lib.ql_gemm_workspace_max_bytes(16384, 2560, 9728, 0) >= lib.ql_gemm_workspace_bytes(600, 2560, 9728, 0) > \
+        lib.ql_gemm_workspace_max_bytes(512, 2560, 9728, 0)
+    assert lib.ql_gemm_workspace_max_bytes(0, 64, 256, 0) == 0
 
 
 def test_ops_refuse_cpu_tensors():

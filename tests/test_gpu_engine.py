@@ -379,6 +379,58 @@ def test_pipelined_decode_matches_step_by_step(tiny_dir):
     llm.model_runner.launch = orig
 
 
+def test_more_running_sequences_than_graph_buckets(tiny_dir):
+    """max_num_seqs above the 512-row staging / graph limit: such batches decode eagerly and step by step (the
+    pipelined loop needs the staged inputs), with the outputs of the small-batch route."""
+    from nanovllm import LLM, SamplingParams
+    llm = LLM(tiny_dir, load_format="dummy", enforce_eager=False, max_model_len=256, max_num_seqs=600,
+              max_num_batched_tokens=4096, quant_type="per_row_weight_only", linear_dtype=torch.int8)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, 1000, (3,), generator=g).tolist() for _ in range(530)]
+    sizes = []
+    orig = llm.model_runner.launch
+    llm.model_runner.launch = lambda seqs, is_prefill, prev=None: (sizes.append((len(seqs), is_prefill, prev is not None)),
+                                                                   orig(seqs, is_prefill, prev=prev))[1]
+    out = llm.generate(prompts, SamplingParams(max_tokens=4, ignore_eos=True))
+    llm.model_runner.launch = orig
+    assert [len(o["token_ids"]) for o in out] == [4] * 530
+    assert any(n > 512 and not pf for n, pf, _ in sizes), "no decode step above the staging limit ran"
+    assert not any(piped for n, pf, piped in sizes if n > 512)
+    small = LLM(tiny_dir, load_format="dummy", enforce_eager=False, max_model_len=256, max_num_seqs=64,
+                quant_type="per_row_weight_only", linear_dtype=torch.int8)
+    ref = small.generate(prompts[:40], SamplingParams(max_tokens=4, ignore_eos=True))
+    assert [o["token_ids"] for o in ref] == [o["token_ids"] for o in out[:40]]
+
+
+def test_captured_graphs_survive_a_workspace_that_is_outgrown(tmp_path):
+    """The decode hipGraphs hold the split-K workspace by address.  When another caller later needs a larger one,
+    the old buffer must stay alive and untouched: graph decode keeps producing the eager tokens.  (The MLP is
+    3072 wide so that down_proj really splits K three ways and uses the workspace.)"""
+    from nanovllm import LLM, SamplingParams, _qlinear as Q
+    tiny_dir = str(tmp_path)
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump(dict(TINY, intermediate_size=3072), f)
+    assert Q.load().ql_gemm_workspace_bytes(4, 256, 3072, 0) > 0
+    sp = SamplingParams(max_tokens=10, ignore_eos=True)
+    kw = dict(load_format="dummy", max_model_len=512, max_num_seqs=16, quant_type="per_row_weight_only",
+              linear_dtype=torch.int8)
+    llm = LLM(tiny_dir, enforce_eager=False, **kw)
+    before = [o["token_ids"] for o in llm.generate(_prompts(), sp)]
+    dev = llm.model_runner.device
+    old = Q.workspace.buf[Q.workspace._key(dev)]
+    Q.workspace.reserve(dev, old.numel() + (8 << 20))             # somebody needs more: a new buffer
+    assert Q.workspace.buf[Q.workspace._key(dev)] is not old
+    assert any(old is b for b in Q.workspace.pinned[Q.workspace._key(dev)])
+    junk = [torch.full((old.numel(),), 0xFF, dtype=torch.uint8, device=dev) for _ in range(4)]   # would land in a freed buffer
+    torch.cuda.synchronize()
+    assert int(old[: 64 * 1024].max()) == 0                       # the ticket counters of the pinned buffer are intact
+    after = [o["token_ids"] for o in llm.generate(_prompts(), sp)]
+    del junk
+    assert after == before
+    eager = LLM(tiny_dir, enforce_eager=True, **kw)
+    assert [o["token_ids"] for o in eager.generate(_prompts(), sp)] == before
+
+
 def test_rccl_allreduce_on_side_stream_is_graph_capturable():
     """The row-parallel reduction (RCCL all-reduce enqueued on a side HIP stream with event fork/join)
     must be capturable into the decode hipGraph.  One GPU here, so the group has a single rank; the

@@ -387,6 +387,36 @@ def test_group_sizes(NQ, g):
                           O.abs_product_sum(xb, deq), what=f"g{g} {dt}")
 
 
+@pytest.mark.parametrize("g", [96, 384, 1152])
+@pytest.mark.parametrize("tile", [None, (1, 1, 8, 8), (2, 2, 4, 8), (1, 4, 2, 16), (2, 4, 2, 4), (4, 8, 1, 4)])
+def test_group_sizes_unrelated_to_the_chunk_length(NQ, g, tile):
+    """Group sizes that neither divide nor are divided by a tile's k chunk (the reference takes any divisor of K,
+    quantization.py:205): quantizer and fake quantizer bit-exact, GEMM at the usual bar, on tiles whose wave
+    chunk is 128, 256 and 512 k."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    M, N, K = 40, 96, 1152
+    rng = np.random.default_rng(g)
+    xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05)
+    wb[3, :g] = 0
+    try:
+        if tile is not None:
+            assert lib.ql_gemm_force_config(*tile, 1) == 0
+        for dt in DTYPES:
+            qo, so = O.per_group_quant(wb, g, dt)
+            q, s = NQ.per_group_quant(bf16_t(wb), g, TDT[dt])
+            assert np.array_equal(bits8(q), qo.view(np.uint8)) and np.array_equal(s.cpu().numpy(), so)
+            assert np.array_equal(bits16(NQ.fake_per_group_quant(bf16_t(wb), g, TDT[dt])), O.fake_per_group_quant(wb, g, dt))
+            y = NQ.per_group_matmul(bf16_t(xb), q, s, None, g, TDT[dt])
+            deq = (O._decode_q(qo, dt).reshape(N, -1, g) * so[..., None]).reshape(N, -1)
+            assert_gemm_close(bits16(y), O.per_group_matmul(xb, qo, so, None, g, dt, return_f64=True),
+                              O.abs_product_sum(xb, deq), what=f"g{g} {dt} {tile}")
+            yt = NQ.per_group_matmul(bf16_t(xb), NQ.tile_weight(q), s, None, g, TDT[dt])
+            assert torch.equal(yt, y)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
 # ----------------------------------------------------------------------------- edge cases / API behaviour
 def test_empty_and_leading_dims(NQ):
     w = torch.randn(64, 128, device="cuda", dtype=torch.bfloat16)
