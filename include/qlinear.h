@@ -104,6 +104,20 @@ int ql_gemm_w8a16(int wdtype, int granularity, const void* x_bf16, const void* q
                   const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ql_gemm_w8a16 for callers that cannot allocate device memory: code under hipGraph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  (No counterpart in the reference, which allocates its outputs and
+ * Triton scratch freely.)  Same arguments, kernels and results, but the split-K workspace is a fixed
+ * QL_NOALLOC_SCRATCH_BYTES array inside the library's code object, one copy per GPU, held until the process
+ * ends; the call neither allocates nor frees anything.  A problem whose plan needs more than that is rejected
+ * with QL_EWORKSPACE (ql_gemm_workspace_bytes tells in advance).  The array keeps the previous call's contents;
+ * the call clears the ticket counters it will use (a small launch on `stream` in front of the GEMM).  All calls on one GPU share
+ * the array: calls that overlap in time on one GPU (different streams, different threads) race.  The first call
+ * on each device looks up the array's address; make it outside stream capture. */
+#define QL_NOALLOC_SCRATCH_BYTES (16u << 20)
+int ql_gemm_w8a16_noalloc(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
+                          const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
+                          void* stream);
+
 /* _per_row_post_process_mm as launched by per_row_matmul (:54-144, :324-345):
  * y[M,N] bf16 = bf16( (sum_k qx[m,k]*qw[n,k]) * sx[m] * sw[n] + bias[n] ), both operands int8
  * (exact int32 accumulation on i8 MFMA) or both fp8-e4m3fn (f32 accumulation on fp8 MFMA).

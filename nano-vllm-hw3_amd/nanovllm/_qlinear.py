@@ -30,6 +30,8 @@ SIGNATURES = {
     "ql_gemm_workspace_max_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_int]),
     "ql_gemm_w8a16": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                _c_int, _c_vp, _c_sz, _c_vp]),
+    "ql_gemm_w8a16_noalloc": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
+                                       _c_int, _c_vp]),
     "ql_gemm_w8a8": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_vp, _c_sz, _c_vp]),
     "ql_gemm_w8a16_silu": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
