@@ -25,7 +25,6 @@ class BlockManager:
     def deallocate(self, seq):
         self.free.extend(reversed(seq.block_table))
         seq.block_table.clear()
-        seq.num_cached_tokens = 0
 
     def can_append(self, seq) -> bool:
         # a new block is needed when the token about to be written starts a block

@@ -116,8 +116,7 @@ class ModelRunner:
             cu.append(cu[-1] + n)
             for i, blk in enumerate(seq.block_table):
                 start = blk * self.block_size
-                cnt = self.block_size if i != seq.num_blocks - 1 else seq.last_block_num_tokens
-                slot_mapping.extend(range(start, start + cnt))
+                slot_mapping.extend(range(start, start + seq.tokens_in_block(i, self.block_size)))
         if not slot_mapping:           # warm-up sequences own no blocks
             slot = None
         else:
@@ -206,7 +205,7 @@ class ModelRunner:
         input_ids = [s.last_token for s in seqs]
         positions = [len(s) - 1 for s in seqs]
         context_lens = [len(s) for s in seqs]
-        slot_mapping = [s.block_table[-1] * self.block_size + s.last_block_num_tokens - 1 for s in seqs]
+        slot_mapping = [s.block_table[-1] * self.block_size + (len(s) - 1) % self.block_size for s in seqs]
         width = max(len(s.block_table) for s in seqs)
         tables = [s.block_table + [0] * (width - len(s.block_table)) for s in seqs]
         return (self._dev(input_ids, torch.int64), self._dev(positions, torch.int64),

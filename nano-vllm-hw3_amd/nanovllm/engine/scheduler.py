@@ -1,7 +1,7 @@
 from collections import deque
 
 from nanovllm.engine.block_manager import BlockManager
-from nanovllm.engine.sequence import Sequence, SequenceStatus
+from nanovllm.engine.sequence import ACTIVE, DONE, QUEUED, Sequence
 
 
 class Scheduler:
@@ -24,43 +24,63 @@ class Scheduler:
         self.waiting.append(seq)
 
     def schedule(self):
-        picked, tokens = [], 0
-        while self.waiting and len(picked) < self.max_num_seqs:
+        """One step's batch: (sequences, is_prefill).  Admission has strict priority over decoding."""
+        batch = self._admit()
+        if batch:
+            return batch, True
+        batch = self._decode_batch()
+        assert batch, "nothing to run: a single sequence does not fit the KV cache"
+        return batch, False
+
+    def _admit(self):
+        """Move requests from the head of the queue into the running set while the sequence count, the token
+        budget of one step and the free KV blocks allow; FIFO, no skipping ahead."""
+        bm, batch, budget = self.block_manager, [], self.max_num_batched_tokens
+        while self.waiting and len(batch) < self.max_num_seqs:
             seq = self.waiting[0]
-            if tokens + len(seq) > self.max_num_batched_tokens or not self.block_manager.can_allocate(seq):
+            if len(seq) > budget or not bm.can_allocate(seq):
                 break
-            self.block_manager.allocate(seq)
-            tokens += len(seq)
-            seq.status = SequenceStatus.RUNNING
             self.waiting.popleft()
-            self.running.append(seq)
-            picked.append(seq)
-        if picked:
-            return picked, True
-        while self.running and len(picked) < self.max_num_seqs:
-            seq = self.running.popleft()
-            while not self.block_manager.can_append(seq):
-                if self.running:
-                    self.preempt(self.running.pop())
-                else:
-                    self.preempt(seq)
+            bm.allocate(seq)
+            budget -= len(seq)
+            seq.state = ACTIVE
+            batch.append(seq)
+        self.running.extend(batch)
+        return batch
+
+    def _decode_batch(self):
+        """Every running sequence gets its next token; when the cache cannot hold one more token for all of
+        them, the most recently admitted ones go back to the head of the queue (their blocks are freed and they
+        will be prefilled again), the sequence under consideration itself last."""
+        bm = self.block_manager
+        keep = []
+        candidates = deque(self.running)
+        while candidates and len(keep) < self.max_num_seqs:
+            seq = candidates.popleft()
+            evicted_self = False
+            while not bm.can_append(seq):
+                victim = candidates.pop() if candidates else seq
+                self.preempt(victim)
+                if victim is seq:
+                    evicted_self = True
                     break
-            else:
-                self.block_manager.may_append(seq)
-                picked.append(seq)
-        assert picked
-        self.running.extendleft(reversed(picked))
-        return picked, False
+            if not evicted_self:
+                bm.may_append(seq)
+                keep.append(seq)
+        self.running = deque(keep + list(candidates))
+        return keep
 
     def preempt(self, seq):
-        seq.status = SequenceStatus.WAITING
+        if seq in self.running:
+            self.running.remove(seq)
         self.block_manager.deallocate(seq)
+        seq.state = QUEUED
         self.waiting.appendleft(seq)
 
     PENDING = 0   # stands in for a token that the GPU is still computing
 
     def _finish(self, seq):
-        seq.status = SequenceStatus.FINISHED
+        seq.state = DONE
         self.block_manager.deallocate(seq)
         self.running.remove(seq)
 

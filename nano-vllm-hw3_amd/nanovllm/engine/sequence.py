@@ -1,44 +1,44 @@
-from copy import copy
-from enum import Enum, auto
-from itertools import count
+"""The per-request record of the engine: what the scheduler, the KV block allocator and the model runner need to
+know about one prompt and its continuation (the counterpart of the reference's nanovllm/engine/sequence.py; no
+prefix-cache fields and no pickling hooks, because every rank keeps its own copy instead of receiving it by RPC)."""
+import itertools
 
 from nanovllm.sampling_params import SamplingParams
 
+_ids = itertools.count()
 
-class SequenceStatus(Enum):
-    WAITING = auto()
-    RUNNING = auto()
-    FINISHED = auto()
+# life cycle of a request
+QUEUED, ACTIVE, DONE = "queued", "active", "done"
 
 
 class Sequence:
-    """One request: prompt + generated tokens + its KV block table (behaviour of the reference's
-    nanovllm/engine/sequence.py, without the prefix-cache bookkeeping)."""
-    block_size = 256
-    counter = count()
+    __slots__ = ("seq_id", "state", "token_ids", "num_tokens", "num_prompt_tokens", "last_token", "block_table",
+                 "max_tokens", "ignore_eos")
 
-    def __init__(self, token_ids, sampling_params: SamplingParams = SamplingParams()):
-        self.seq_id = next(Sequence.counter)
-        self.status = SequenceStatus.WAITING
-        self.token_ids = copy(token_ids)
-        self.last_token = token_ids[-1]
-        self.num_tokens = len(token_ids)
-        self.num_prompt_tokens = len(token_ids)
-        self.num_cached_tokens = 0
-        self.block_table = []
-        self.temperature = sampling_params.temperature
-        self.max_tokens = sampling_params.max_tokens
-        self.ignore_eos = sampling_params.ignore_eos
+    def __init__(self, token_ids, sampling_params: SamplingParams = None):
+        sp = sampling_params if sampling_params is not None else SamplingParams()
+        ids = list(token_ids)
+        assert ids, "a request needs at least one prompt token"
+        self.seq_id = next(_ids)
+        self.state = QUEUED
+        self.token_ids = ids                    # prompt followed by the generated tokens
+        self.num_prompt_tokens = self.num_tokens = len(ids)
+        self.last_token = ids[-1]
+        self.block_table = []                   # KV blocks, in order of the tokens they hold
+        self.max_tokens = sp.max_tokens         # (the sampler is greedy: the temperature is not used)
+        self.ignore_eos = sp.ignore_eos
 
     def __len__(self):
         return self.num_tokens
 
-    def __getitem__(self, key):
-        return self.token_ids[key]
+    def append_token(self, token_id: int):
+        self.token_ids.append(token_id)
+        self.last_token = token_id
+        self.num_tokens += 1
 
     @property
     def is_finished(self):
-        return self.status == SequenceStatus.FINISHED
+        return self.state == DONE
 
     @property
     def num_completion_tokens(self):
@@ -48,15 +48,6 @@ class Sequence:
     def completion_token_ids(self):
         return self.token_ids[self.num_prompt_tokens:]
 
-    @property
-    def num_blocks(self):
-        return (self.num_tokens + self.block_size - 1) // self.block_size
-
-    @property
-    def last_block_num_tokens(self):
-        return self.num_tokens - (self.num_blocks - 1) * self.block_size
-
-    def append_token(self, token_id: int):
-        self.token_ids.append(token_id)
-        self.last_token = token_id
-        self.num_tokens += 1
+    def tokens_in_block(self, i: int, block_size: int) -> int:
+        """How many of this sequence's tokens live in its i-th KV block."""
+        return min(block_size, self.num_tokens - i * block_size)

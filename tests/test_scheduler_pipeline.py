@@ -14,9 +14,9 @@ from nanovllm.sampling_params import SamplingParams      # noqa: E402
 EOS = 7
 
 
-def _cfg(blocks=64, max_num_seqs=8):
-    return types.SimpleNamespace(max_num_seqs=max_num_seqs, max_num_batched_tokens=4096, eos=EOS,
-                                 num_kvcache_blocks=blocks, kvcache_block_size=256)
+def _cfg(blocks=64, max_num_seqs=8, block_size=256, budget=4096):
+    return types.SimpleNamespace(max_num_seqs=max_num_seqs, max_num_batched_tokens=budget, eos=EOS,
+                                 num_kvcache_blocks=blocks, kvcache_block_size=block_size)
 
 
 def _model(seq, pos):
@@ -24,8 +24,8 @@ def _model(seq, pos):
     return (seq.token_ids[0] * 31 + pos * 17) % 11
 
 
-def _run(pipelined, specs):
-    sch = Scheduler(_cfg())
+def _run(pipelined, specs, cfg=None, log=None):
+    sch = Scheduler(cfg or _cfg())
     seqs = [Sequence([p, 1, 2], SamplingParams(max_tokens=m, ignore_eos=ig)) for p, m, ig in specs]
     for s in seqs:
         sch.add(s)
@@ -43,6 +43,8 @@ def _run(pipelined, specs):
             drain(pending); pending = None
             continue
         batch, is_prefill = sch.schedule()
+        if log is not None:
+            log.append((is_prefill, [s.seq_id for s in batch], sum(len(b.block_table) for b in batch)))
         toks = [_model(s, len(s)) for s in batch]        # what the GPU would produce for this launch
         idx = sch.advance(batch)
         if pending is not None:
@@ -81,3 +83,34 @@ def test_commit_drops_token_launched_beyond_an_eos():
     assert s.is_finished and s.completion_token_ids == [5, EOS] and s.last_token == EOS
     assert sch.commit(b2, i2, [4]) == []                 # the late token is ignored
     assert s.completion_token_ids == [5, EOS] and sch.is_finished()
+
+
+def test_admission_limits_and_prefill_priority():
+    """A step is all-prefill or all-decode; admission is FIFO and stops at the sequence limit, at the token budget
+    of one step, or when the KV blocks run out; waiting requests are admitted before anything decodes."""
+    log = []
+    specs = [(i + 1, 3, True) for i in range(7)]
+    out = _run(False, specs, _cfg(max_num_seqs=3, budget=8), log)          # 3-token prompts: two fit the 8-token budget
+    assert [len(o) for o in out] == [3] * 7
+    prefills = [ids for pf, ids, _ in log if pf]
+    assert all(len(ids) <= 2 for ids in prefills) and sum(len(i) for i in prefills) == 7
+    first_decode = next(i for i, (pf, _, _) in enumerate(log) if not pf)
+    assert all(pf for pf, _, _ in log[:first_decode]) and first_decode == 4  # 2+2+2+1 admitted before any decode
+    assert all(len(ids) <= 3 for pf, ids, _ in log if not pf)                # decode steps respect max_num_seqs
+
+
+def test_preemption_under_kv_pressure_gives_the_same_tokens():
+    """With too few KV blocks the most recently admitted sequences are pushed back to the head of the queue and
+    prefilled again later; outputs equal those of an unconstrained run and every block is returned."""
+    specs = [(3, 14, True), (4, 14, True), (5, 9, True), (6, 14, False), (8, 11, True)]
+    roomy = _run(False, specs, _cfg(blocks=64, block_size=4))
+    log = []
+    tight = _run(False, specs, _cfg(blocks=7, block_size=4), log)
+    assert tight == roomy
+    seen, again = set(), 0
+    for pf, ids, _ in log:
+        if pf:
+            again += sum(1 for i in ids if i in seen)
+            seen.update(ids)
+    assert again > 0, "the pool was never tight enough to preempt"
+    assert _run(True, specs, _cfg(blocks=7, block_size=4)) == roomy           # and with the one-deep pipeline
