@@ -51,17 +51,23 @@ def gemm_bytes(M, N, K, n_out=None):
     return N * K + 4 * N + 2 * M * K + 2 * M * (N if n_out is None else n_out)
 
 
-TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r01_decode_gemm_traffic.json")
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r02_decode_gemm_traffic.json")
 
 
 def pmc_traffic(mods4, buckets):
     """HBM-side bytes per launch, weighted over the same (batch bucket, layer shape) mix as `achieved`, from
     the committed rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950 requires, + WRITE_SIZE; see
     tools/pmc_traffic.py).  Counters cannot be read from inside this process, hence the table; null when
-    the table is missing or the model is not the one it was measured on."""
+    the table is missing, was taken on other kernel sources than this tree's, or the model is not the one it was
+    measured on."""
     if not os.path.exists(TRAFFIC_TABLE):
         return None
-    table = json.load(open(TRAFFIC_TABLE))["traffic_bytes"]
+    doc = json.load(open(TRAFFIC_TABLE))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_traffic import kernel_fingerprint
+    if doc.get("kernel_sources_sha256") != kernel_fingerprint():
+        return None                  # measured on other kernel sources than the ones this tree builds: stale
+    table = doc["traffic_bytes"]
     names = ["qkv", "o", "gate_up_silu", "down"]
     want = {"qkv": (4096, 1024), "o": (1024, 2048), "gate_up_silu": (6144, 1024), "down": (1024, 3072)}
     for nm, m in zip(names, mods4):

@@ -20,10 +20,11 @@ def divide(a: int, b: int) -> int:
 
 
 class _SideStreamAllReduce:
-    """Row-parallel partial sums are reduced with RCCL on a dedicated HIP stream so that the
-    collective of one M-slab overlaps the GEMM of the next (prefill); decode-sized outputs go in
-    one piece.  Event fork/join keeps the result ordered with the compute stream and the pattern is
-    capturable into a hipGraph (it only records events and enqueues work)."""
+    """Row-parallel partial sums are reduced with RCCL on a dedicated HIP stream.  A decode-sized output goes in
+    one piece (fork, all-reduce, join: nothing else can run before the sum exists).  A prefill-sized output is
+    produced in row slabs (reduce_slabs): slab i is all-reduced on the side stream while the compute stream
+    already runs the GEMM of slab i+1, so only the last slab's collective is exposed.  Both forms only record
+    events and enqueue work, so they can be captured into a hipGraph."""
 
     def __init__(self):
         self.stream = None
@@ -33,15 +34,19 @@ class _SideStreamAllReduce:
             self.stream = torch.cuda.Stream(device=device)
         return self.stream
 
+    @staticmethod
+    def _host_reduce(y):
+        # test transport (several ranks sharing one GPU): gloo moves host memory
+        h = y.cpu()
+        dist.all_reduce(h)
+        y.copy_(h)
+
     def reduce_(self, y: torch.Tensor):
         if not y.is_cuda:
             dist.all_reduce(y)
             return y
         if dist.get_backend() == "gloo":
-            # test transport (several ranks sharing one GPU): gloo moves host memory
-            h = y.cpu()
-            dist.all_reduce(h)
-            y.copy_(h)
+            self._host_reduce(y)
             return y
         main = torch.cuda.current_stream(y.device)
         side = self.side(y.device)
@@ -51,13 +56,51 @@ class _SideStreamAllReduce:
         main.wait_stream(side)
         return y
 
+    def reduce_slabs(self, y: torch.Tensor, bounds, produce):
+        """``produce(a, b)`` enqueues the computation of rows [a, b) of ``y`` on the current stream; every slab
+        is summed over the TP group as soon as it exists, overlapping the production of the next one."""
+        if not y.is_cuda or dist.get_backend() == "gloo":
+            for a, b in bounds:
+                produce(a, b)
+                if y.is_cuda:
+                    self._host_reduce(y[a:b])
+                else:
+                    dist.all_reduce(y[a:b])
+            return y
+        main = torch.cuda.current_stream(y.device)
+        side = self.side(y.device)
+        for a, b in bounds:
+            produce(a, b)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)                     # the side stream waits for THIS slab only
+            with torch.cuda.stream(side):
+                dist.all_reduce(y[a:b])
+        main.wait_stream(side)
+        return y
+
 
 _allreduce = _SideStreamAllReduce()
+
+# rows per slab of a pipelined row-parallel output, and the row count from which slabs are used
+TP_SLAB_ROWS = 2048
+TP_SLAB_MIN_ROWS = 4096
 
 
 def tp_all_reduce(y: torch.Tensor) -> torch.Tensor:
     """Sum a row-parallel partial output over the TP group (reference: linear.py:151-152)."""
     return _allreduce.reduce_(y)
+
+
+def tp_slab_bounds(m: int):
+    """Row ranges of a pipelined row-parallel output, or None when the output goes in one piece."""
+    if m < TP_SLAB_MIN_ROWS:
+        return None
+    return [(a, min(a + TP_SLAB_ROWS, m)) for a in range(0, m, TP_SLAB_ROWS)]
+
+
+def tp_all_reduce_slabs(y: torch.Tensor, bounds, produce) -> torch.Tensor:
+    return _allreduce.reduce_slabs(y, bounds, produce)
 
 
 class LinearBase(nn.Module):
@@ -153,7 +196,17 @@ class RowParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(1, self.tp_rank * k, k))
 
     def forward(self, x):
-        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        bias = self.bias if self.tp_rank == 0 else None
+        if self.tp_size > 1:
+            x2 = x.reshape(-1, x.shape[-1])
+            bounds = tp_slab_bounds(x2.shape[0])
+            if bounds is not None:
+                y = torch.empty((x2.shape[0], self.weight.shape[0]), dtype=x.dtype, device=x.device)
+
+                def produce(a, b):
+                    y[a:b] = F.linear(x2[a:b], self.weight, bias)
+                return tp_all_reduce_slabs(y, bounds, produce).view(*x.shape[:-1], -1)
+        y = F.linear(x, self.weight, bias)
         if self.tp_size > 1:
             y = tp_all_reduce(y)
         return y

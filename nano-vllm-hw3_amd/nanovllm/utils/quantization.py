@@ -128,7 +128,7 @@ def _wcode(qw, dtype):
     return Q.dtype_code(dtype) | (Q.QL_TILED if isinstance(qw, TiledWeight) else 0)
 
 
-def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False):
+def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False, out=None):
     assert dtype in _DTYPES and qw.dtype == dtype
     x2, y_shape = _flatten(x, qw.shape[0] // 2 if silu else qw.shape[0])
     Q.require_cuda(x2, torch.bfloat16, "x")
@@ -147,40 +147,45 @@ def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False):
                                        bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                                        group_size or 0, Q.stream_ptr(x.device)))
         return y.view(y_shape)
-    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    if out is not None:
+        assert out.shape == (M, N)
+        y = Q.require_cuda(out, torch.bfloat16, "out")
+    else:
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     ws_ptr, ws_len = Q.workspace.get(x.device, lib.ql_gemm_workspace_bytes(M, N, K, granularity))
     Q.check(lib.ql_gemm_w8a16(_wcode(qw, dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
                               bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                               group_size or 0, ws_ptr, ws_len, Q.stream_ptr(x.device)))
-    return y.view(y_shape)
+    return y if out is not None else y.view(y_shape)
 
 
 @torch.no_grad()
-def per_tensor_matmul(x, qw, sw, bias, dtype, silu=False):
-    """``(x.float() @ (qw.float() * sw).T).to(bf16) + bias`` fused (quantization.py:237-262)."""
-    return _w8a16(x, qw, sw, bias, Q.QL_PER_TENSOR, 0, dtype, silu)
+def per_tensor_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
+    """``(x.float() @ (qw.float() * sw).T).to(bf16) + bias`` fused (quantization.py:237-262).  ``out`` (every
+    matmul here): a contiguous [M, N] bf16 tensor to write instead of a new one (x is then [M, K])."""
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_TENSOR, 0, dtype, silu, out)
 
 
 @torch.no_grad()
-def per_group_matmul(x, qw, sw, bias, group_size, dtype, silu=False):
+def per_group_matmul(x, qw, sw, bias, group_size, dtype, silu=False, out=None):
     """Per-group dequant fused into the GEMM (quantization.py:265-307)."""
     assert qw.shape[1] % group_size == 0
-    return _w8a16(x, qw, sw, bias, Q.QL_PER_GROUP, group_size, dtype, silu)
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_GROUP, group_size, dtype, silu, out)
 
 
 @torch.no_grad()
-def per_row_weight_only_matmul(x, qw, sw, bias, dtype, silu=False):
+def per_row_weight_only_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
     """W8A16 with per-output-channel scales: ``bf16((x @ q.T) * sw + bias)``; the numerics the
     reference reaches through ``F.linear(x, fake_per_row_quant(W))`` (quantization.py:438-439).
 
     ``silu=True`` (every matmul here): qw / sw / bias rows are in the interleaved gate/up strip order
     of ``interleave_gate_up`` and the result is ``silu(gate) * up`` of shape [..., N/2], bit-identical
     to the plain matmul on the un-interleaved weight followed by SiluAndMul."""
-    return _w8a16(x, qw, sw, bias, Q.QL_PER_ROW, 0, dtype, silu)
+    return _w8a16(x, qw, sw, bias, Q.QL_PER_ROW, 0, dtype, silu, out)
 
 
 @torch.no_grad()
-def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False):
+def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False, out=None):
     """The dual-scale GEMM on already-quantized activations (quantization.py:54-144, 331-345)."""
     assert dtype in _DTYPES
     Q.require_cuda(qx, dtype, "qx")
@@ -199,7 +204,11 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False):
                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                                       Q.stream_ptr(qx.device)))
         return y if y_shape is None else y.view(y_shape)
-    y = torch.empty((M, N), dtype=torch.bfloat16, device=qx.device)
+    if out is not None:
+        assert out.shape == (M, N)
+        y = Q.require_cuda(out, torch.bfloat16, "out")
+    else:
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=qx.device)
     ws_ptr, ws_len = Q.workspace.get(qx.device, lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW))
     Q.check(lib.ql_gemm_w8a8(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
                              bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K, ws_ptr, ws_len,
@@ -208,12 +217,12 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False):
 
 
 @torch.no_grad()
-def per_row_matmul(x, qw, sw, bias, dtype, silu=False):
+def per_row_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
     """Dynamic per-token activation quant + W8A8 GEMM (quantization.py:310-346)."""
     x2, y_shape = _flatten(x, qw.size(0) // 2 if silu else qw.size(0))
     assert x2.size(1) % 32 == 0, f"K({x2.size(1)}) must be multiple of 32"
     qx, sx = per_row_quant(x2.contiguous(), dtype)
-    return w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape, silu)
+    return w8a8_matmul(qx, sx, qw, sw, bias, dtype, None if out is not None else y_shape, silu, out)
 
 
 def interleave_gate_up(t: torch.Tensor):
@@ -291,6 +300,22 @@ class _QBase(torch.nn.Module):
             y = tp_all_reduce(y)
         return y
 
+    def _run(self, x, matmul):
+        """``matmul(rows, out)`` runs the module's GEMM on ``x[rows]`` (rows=None: all of x, whatever its leading
+        dims; out=None: allocate).  A row-parallel shard under TP with a prefill-sized input produces its partial
+        output in row slabs, each all-reduced on the side stream while the next slab's GEMM runs
+        (linear.py::_SideStreamAllReduce.reduce_slabs); everything else is one GEMM followed, for row-parallel
+        shards, by one all-reduce."""
+        if self.tp_dim == 1 and self.tp_size > 1 and not self.silu_fused:
+            from nanovllm.layers.linear import tp_all_reduce_slabs, tp_slab_bounds
+            m = x.numel() // x.shape[-1]
+            bounds = tp_slab_bounds(m)
+            if bounds is not None:
+                y = torch.empty((m, self.qw.shape[0]), dtype=torch.bfloat16, device=x.device)
+                tp_all_reduce_slabs(y, bounds, lambda a, b: matmul(slice(a, b), y[a:b]))
+                return y.view(*x.shape[:-1], -1)
+        return self._finish(matmul(None, None))
+
 
 class QLinear(_QBase):
     """Per-row quantized Linear layer (reference: quantization.py:349-364).  ``weight_only=False`` is
@@ -324,7 +349,9 @@ class QLinear(_QBase):
 
     def forward(self, x: torch.Tensor):
         fn = per_row_weight_only_matmul if self.weight_only else per_row_matmul
-        return self._finish(fn(x, self.qw, self.sw, self._bias_for_rank(), self.dtype, self.silu_fused))
+        x2 = x.reshape(-1, x.shape[-1])
+        return self._run(x, lambda rows, out: fn(x if rows is None else x2[rows], self.qw, self.sw,
+                                                 self._bias_for_rank(), self.dtype, self.silu_fused, out))
 
     @property
     def takes_quantized_input(self):
@@ -335,7 +362,9 @@ class QLinear(_QBase):
     def forward_quantized(self, qx: torch.Tensor, sx: torch.Tensor):
         """forward() on activations already quantized per row: qx [M, K] in self.dtype, sx [M] f32."""
         assert not self.weight_only
-        return self._finish(w8a8_matmul(qx, sx, self.qw, self.sw, self._bias_for_rank(), self.dtype, None, self.silu_fused))
+        return self._run(qx, lambda rows, out: w8a8_matmul(
+            qx if rows is None else qx[rows], sx if rows is None else sx[rows], self.qw, self.sw,
+            self._bias_for_rank(), self.dtype, None, self.silu_fused, out))
 
 
 class QTensorLinear(_QBase):
@@ -368,8 +397,9 @@ class QTensorLinear(_QBase):
         return m
 
     def forward(self, x: torch.Tensor):
-        return self._finish(per_tensor_matmul(x, self.qw, self._sw32, self._bias_for_rank(), self.dtype,
-                                              self.silu_fused))
+        x2 = x.reshape(-1, x.shape[-1])
+        return self._run(x, lambda rows, out: per_tensor_matmul(x if rows is None else x2[rows], self.qw, self._sw32,
+                                                                self._bias_for_rank(), self.dtype, self.silu_fused, out))
 
 
 class QGroupLinear(_QBase):
@@ -401,8 +431,10 @@ class QGroupLinear(_QBase):
         return m
 
     def forward(self, x: torch.Tensor):
-        return self._finish(per_group_matmul(x, self.qw, self.sw, self._bias_for_rank(), self.group_size, self.dtype,
-                                             self.silu_fused))
+        x2 = x.reshape(-1, x.shape[-1])
+        return self._run(x, lambda rows, out: per_group_matmul(x if rows is None else x2[rows], self.qw, self.sw,
+                                                               self._bias_for_rank(), self.group_size, self.dtype,
+                                                               self.silu_fused, out))
 
 
 # --------------------------------------------------------------------------- fake quant

@@ -39,11 +39,15 @@ def _install_oracle_doubles():
         q, s = O.per_row_quant(bits(x), "int8")
         return torch.from_numpy(q), torch.from_numpy(s)
 
-    def w8a16(x, qw, sw, bias, dtype, silu=False):
+    def w8a16(x, qw, sw, bias, dtype, silu=False, out=None):
         assert not silu
         x2 = x.reshape(-1, x.shape[-1])
         y = O.w8a16_rowscale_matmul(bits(x2), qw.numpy(), sw.numpy(), None if bias is None else bits(bias), "int8")
-        return torch.from_numpy(y.view(np.int16)).view(torch.bfloat16).reshape(*x.shape[:-1], qw.shape[0])
+        y = torch.from_numpy(y.view(np.int16)).view(torch.bfloat16)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y.reshape(*x.shape[:-1], qw.shape[0])
 
     NQ.per_row_quant = per_row_quant
     NQ.per_row_weight_only_matmul = w8a16
@@ -134,6 +138,14 @@ def _worker_forward(rank, world, port):
         err = (yr.float() - y1.float()).abs().max() / y1.float().abs().max()
         assert err < 0.03, float(err)
         assert (yr.float() - ref.float()).abs().max() / ref.float().abs().max() < 0.05
+        # a prefill-sized input goes through in row slabs, each reduced as soon as it exists: same result
+        # (slab limits lowered so that 5 rows make three slabs), for the quantized and the bf16 module
+        L.TP_SLAB_ROWS, L.TP_SLAB_MIN_ROWS = 2, 4
+        assert L.tp_slab_bounds(5) == [(0, 2), (2, 4), (4, 5)] and L.tp_slab_bounds(3) is None
+        assert torch.equal(qrow(h_shard), yr)
+        assert torch.equal(qrow(h_shard.view(1, M, -1)), yr.view(1, M, -1))
+        assert torch.equal(row(h_shard), y_row)
+        L.TP_SLAB_ROWS, L.TP_SLAB_MIN_ROWS = 2048, 4096
         # bias really is applied once: removing it changes the result by exactly one bias (to rounding)
         qrow.bias = None
         yr_nb = qrow(h_shard)

@@ -33,6 +33,17 @@ def run():
                 torch.cuda.synchronize()          # one dispatch at a time: the counter pass drops records otherwise
 
 
+def kernel_fingerprint():
+    """sha256 over the sources the decode GEMM is built from: a traffic table is only quoted for the kernels it
+    was measured on (bench.py compares this with the tree it runs from)."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nano-vllm-hw3_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("ql_common.h", "ql_gemm_kernel.h", "ql_gemm.hip"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
 def read(d, counter):
     f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if "qgemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
@@ -47,7 +58,7 @@ def parse(fetch_dir, write_dir):
     out = {"note": "HBM-side bytes per launch of the decode W8A16 GEMM from rocprofv3 PMC passes (tools/pmc_traffic.py): "
                    "traffic = 2 * FETCH_SIZE (gfx950 reports half the bytes of 16-B-per-lane streaming reads) + WRITE_SIZE, "
                    "both in KiB units; median of 5 launches on distinct weight copies",
-           "traffic_bytes": {}}
+           "kernel_sources_sha256": kernel_fingerprint(), "traffic_bytes": {}}
     i = 0
     for name, N, K in SHAPES:
         out["traffic_bytes"][name] = {}
