@@ -51,6 +51,9 @@ class Config:
     # opt-in, off by default because it changes the logits the reference computes in bf16: the vocabulary
     # projection (311 MB of bf16 per decode step for Qwen3-0.6B) as a per-row weight-only quantized linear
     quantize_lm_head: bool = False
+    # "cuda" = the product path (HIP kernels).  "cpu" = plumbing only: the UNQUANTIZED model with plain torch
+    # operators, eager, for checking engine wiring on a host without a GPU; every quantized option is refused there.
+    device: str = "cuda"
 
     def __post_init__(self):
         assert os.path.isdir(self.model), f"{self.model} is not a directory"
@@ -59,6 +62,13 @@ class Config:
         self.hf_config = load_hf_config(self.model)
         self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)
         assert self.max_num_batched_tokens >= self.max_model_len
+        assert self.device in ("cuda", "cpu")
+        if self.device == "cpu":
+            quantized = (self.quant_type is not None or self.weight_quant_fn is not None or self.quantize_lm_head or
+                         self.linear_dtype != torch.bfloat16 or self.load_format == "quantized")
+            assert not quantized, "the quantized-linear path is HIP only: device='cpu' runs the unquantized model"
+            assert self.tensor_parallel_size == 1
+            self.enforce_eager = True
         if self.hf_config.__dict__.get("eos_token_id") is not None and self.eos == -1:
             e = self.hf_config.eos_token_id
             self.eos = e[0] if isinstance(e, (list, tuple)) else e

@@ -19,7 +19,8 @@ class ModelRunner:
         self.enforce_eager = config.enforce_eager
         self.world_size = config.tensor_parallel_size
         self.rank = rank
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.on_gpu = config.device == "cuda"
+        self.device = torch.device("cuda", torch.cuda.current_device()) if self.on_gpu else torch.device("cpu")
         default_dtype = torch.get_default_dtype()
         torch.set_default_dtype(hf.torch_dtype)
         torch.set_default_device(self.device)
@@ -39,9 +40,16 @@ class ModelRunner:
                 # quantization happens after loading, before warm-up and graph capture (reference:
                 # nanovllm/engine/model_runner.py:36-57)
                 apply_quant_from_config(self.model, config)
+            self.graphs = {}
+            if not self.on_gpu:
+                # plumbing mode: unquantized model, plain torch operators, eager, no staging buffers
+                self.allocate_kv_cache()
+                self._stage_max_bs = self._stage_max_blocks = 0
+                self._stage_rows = []
+                self._tok_host = [torch.zeros(0, dtype=torch.int64)]
+                return
             self._reserve_gemm_workspace()
             self.allocate_kv_cache()
-            self.graphs = {}
             from nanovllm import ops
             ops.reserve_attn_workspace(min(config.max_num_seqs, 512), hf.num_attention_heads // self.world_size,
                                        hf.num_key_value_heads // self.world_size, self.block_size,
@@ -82,11 +90,14 @@ class ModelRunner:
 
     def allocate_kv_cache(self):
         cfg, hf = self.config, self.config.hf_config
-        free, total = torch.cuda.mem_get_info()
         num_kv_heads = hf.num_key_value_heads // self.world_size
         block_bytes = 2 * hf.num_hidden_layers * self.block_size * num_kv_heads * hf.head_dim * hf.torch_dtype.itemsize
-        # activations of the largest prefill batch stay well under 10 GiB for every supported size
-        budget = int(free - (1.0 - cfg.gpu_memory_utilization) * total) - (10 << 30)
+        if self.on_gpu:
+            free, total = torch.cuda.mem_get_info()
+            # activations of the largest prefill batch stay well under 10 GiB for every supported size
+            budget = int(free - (1.0 - cfg.gpu_memory_utilization) * total) - (10 << 30)
+        else:
+            budget = 1 << 30                                     # host plumbing runs: a small cache is plenty
         max_needed = cfg.max_num_seqs * ((cfg.max_model_len + self.block_size - 1) // self.block_size)
         cfg.num_kvcache_blocks = max(1, min(budget // block_bytes, max_needed))
         if self.world_size > 1:
@@ -103,12 +114,14 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ per-step input preparation
     def _dev(self, data, dtype):
+        if not self.on_gpu:
+            return torch.tensor(data, dtype=dtype)
         return torch.tensor(data, dtype=dtype, pin_memory=True).to(self.device, non_blocking=True)
 
     def prepare_prefill(self, seqs):
         input_ids, positions, slot_mapping, cu = [], [], [], [0]
         # (re)prefilled sequences may own different blocks than the decode staging rows remember
-        self._stage_rows = [[None] * self._stage_max_bs for _ in range(2)]
+        self._stage_rows = [[None] * self._stage_max_bs for _ in range(2)] if self.on_gpu else []
         for seq in seqs:
             n = len(seq)
             input_ids.extend(seq.token_ids)
@@ -162,7 +175,7 @@ class ModelRunner:
 
     def can_stage(self, seqs):
         """True when a decode step over ``seqs`` fits the staging buffers (what pipelined decode needs)."""
-        return (len(seqs) <= self._stage_max_bs and
+        return (self.on_gpu and len(seqs) <= self._stage_max_bs and
                 all(len(s.block_table) + 1 <= self._stage_max_blocks for s in seqs))
 
     def prepare_decode(self, seqs, perm=None):
@@ -243,6 +256,8 @@ class ModelRunner:
                 self.graphs[gbs].replay()
                 logits = gv["logits"][:bs]
         # greedy sampler (layers/sampler.py:10-12)
+        if not self.on_gpu:
+            return dict(seqs=list(seqs), tokens=logits.float().argmax(dim=-1), host=None, event=None)
         if logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0 and logits.is_contiguous():
             from nanovllm import ops
             tokens = ops.argmax_rows(logits)

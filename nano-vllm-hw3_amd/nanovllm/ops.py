@@ -3,12 +3,17 @@ decode attention).  GPU only; every call is one kernel launch on the current str
 import torch
 
 from nanovllm import _qlinear as Q
+from nanovllm import cpu_ops
 
 BF16 = torch.bfloat16
+# Operators of the UNQUANTIZED model also accept CPU tensors (plain torch, nanovllm/cpu_ops.py: engine plumbing on
+# a host without a GPU); add_rmsnorm_quant and everything in utils/quantization.py stay GPU only.
 
 
 def add_rmsnorm(x, residual, weight, eps):
     """Returns (normed, new_residual); new_residual is x when residual is None."""
+    if not x.is_cuda:
+        return cpu_ops.add_rmsnorm(x, residual, weight, eps)
     Q.require_cuda(x, BF16, "x")
     H = x.shape[-1]
     T = x.numel() // H
@@ -44,6 +49,8 @@ def add_rmsnorm_quant(x, residual, weight, eps, dtype):
 
 
 def silu_mul(x):
+    if not x.is_cuda:
+        return cpu_ops.silu_mul(x)
     Q.require_cuda(x, BF16, "x")
     I = x.shape[-1] // 2
     T = x.numel() // (2 * I)
@@ -56,6 +63,9 @@ def qknorm_rope_store(qkv, positions, cos_sin, q_norm_w, k_norm_w, eps, num_head
                       k_cache=None, v_cache=None, slot_mapping=None, want_kv=True):
     """qkv [T, (Hq+2Hkv)*D] -> q [T,Hq,D] (and contiguous k, v [T,Hkv,D] when want_kv), writing k/v into
     the paged cache rows named by slot_mapping."""
+    if not qkv.is_cuda:
+        return cpu_ops.qknorm_rope_store(qkv, positions, cos_sin, q_norm_w, k_norm_w, eps, num_heads, num_kv_heads,
+                                         head_dim, k_cache, v_cache, slot_mapping, want_kv)
     Q.require_cuda(qkv, BF16, "qkv")
     T = qkv.shape[0]
     q = torch.empty((T, num_heads, head_dim), dtype=BF16, device=qkv.device)
@@ -83,6 +93,8 @@ def reserve_attn_workspace(max_batch, num_heads, num_kv_heads, block_size, max_b
 
 def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale):
     """q [B,Hq,D]; caches [num_blocks, block_size, Hkv, D] -> out [B,Hq,D]."""
+    if not q.is_cuda:
+        return cpu_ops.paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale)
     Q.require_cuda(q, BF16, "q")
     B, Hq, D = q.shape
     _, block_size, Hkv, _ = k_cache.shape
@@ -100,6 +112,8 @@ def attn_prefill(q, k, v, cu_seqlens, max_seqlen, scale):
     """Causal self-attention over packed sequences: q [T,Hq,D], k/v [T,Hkv,D], cu_seqlens int32 [S+1] on
     the device (sequence s owns rows cu[s]:cu[s+1]) -> out [T,Hq,D].  The varlen call of the reference's
     prefill branch (nanovllm/layers/attention.py:64-69) without a prefix cache."""
+    if not q.is_cuda:
+        return cpu_ops.attn_prefill(q, k, v, cu_seqlens, max_seqlen, scale)
     Q.require_cuda(q, BF16, "q")
     Q.require_cuda(k, BF16, "k")
     Q.require_cuda(v, BF16, "v")

@@ -40,16 +40,17 @@ def init_dummy_weights(model, cfg, seed: int = 0, std: float = 0.02):
     checkpoint are drawn in a fixed order from one seeded generator and passed through the same
     weight loaders a real checkpoint goes through, so every tensor-parallel rank holds its shard of
     the same model and TP=N reproduces TP=1 up to reduction order."""
-    g = torch.Generator(device="cuda").manual_seed(seed)
+    dev = next(model.parameters()).device
+    g = torch.Generator(device=dev).manual_seed(seed)
     params = dict(model.named_parameters())
     H, D, I = cfg.hidden_size, cfg.head_dim, cfg.intermediate_size
     Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
 
     def rnd(*shape):
-        return (torch.randn(shape, generator=g, device="cuda", dtype=torch.float32) * std).to(cfg.torch_dtype)
+        return (torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * std).to(cfg.torch_dtype)
 
     def ones(n):
-        return torch.ones(n, device="cuda", dtype=cfg.torch_dtype)
+        return torch.ones(n, device=dev, dtype=cfg.torch_dtype)
 
     _assign(model, params, "model.embed_tokens.weight", rnd(cfg.vocab_size, H))
     if not cfg.tie_word_embeddings:
