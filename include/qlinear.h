@@ -141,6 +141,24 @@ int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x_bf16, const vo
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
                       const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* The qkv projection with everything between it and attention fused into the GEMM epilogue
+ * (Qwen3Attention.forward, nanovllm/models/qwen3.py:80-88: qkv_proj, split, q_norm / k_norm, rotary_emb, and the
+ * store_kvcache of nanovllm/layers/attention.py:10-40, 52-58): the [M, N] projection is never written; every
+ * 128-column head of it goes through exactly the arithmetic of ql_qknorm_rope_store (whose arguments these are)
+ * on the bf16 values ql_gemm_w8a16 / ql_gemm_w8a8 would have stored, so q_out, k_out, v_out and the cache rows are
+ * bit-identical to the GEMM followed by that operator when both run the same tile.  N must equal
+ * (Hq + 2 Hkv) * 128.  Workspace as for the plain GEMMs (ql_gemm_workspace_bytes covers both). */
+int ql_gemm_w8a16_rope(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
+                       const void* bias_bf16, int64_t M, int64_t N, int64_t K, int group, const int64_t* positions,
+                       const float* cos_sin, const void* q_norm_w, const void* k_norm_w, float eps, void* q_out,
+                       void* k_out, void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int Hq,
+                       int Hkv, int head_dim, void* workspace, size_t workspace_bytes, void* stream);
+int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
+                      const void* bias_bf16, int64_t M, int64_t N, int64_t K, const int64_t* positions,
+                      const float* cos_sin, const void* q_norm_w, const void* k_norm_w, float eps, void* q_out,
+                      void* k_out, void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int Hq,
+                      int Hkv, int head_dim, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Tuning hook for benchmarks/tests: force the tile configuration of the next GEMM calls made by
  * this thread.  mt = 32-row fragments per wave (1,2,4,8), wn x wk = how the block's 4 waves split
  * N and K ((4,1),(2,2),(1,4)), cp = 32-k steps a wave loads per chunk (2,4,8), split_k = K slices

@@ -20,7 +20,7 @@ static bool tile_built(int mt, int wn, int wk, int cp, bool group) {
 
 struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; };
 
-static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false) {
+static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false, bool rope = false) {
     Plan pl;
     // Tile ladder, smallest to largest output tile.  On a 256-CU chip these GEMMs are bound by
     // instruction issue and L2->LDS traffic per workgroup, not by HBM or MFMA peak, so the measured
@@ -63,7 +63,19 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
         // per MFMA (measured +25 % at M = 16384); 128-k chunks give its loads a whole chunk of MFMAs to land
         if (!group && ((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = 4; }
     }
-    if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group) && !(silu && (f_wn & 1))) {
+    if (rope) {
+        // the q/k norm + RoPE epilogue needs whole 128-column heads in one workgroup (4 or 8 column strips).
+        // Decode sizes: the 32 x 128 eight-wave tile with the whole K (up to 1024) of a workgroup in flight at once;
+        // from two rounds of those on, 64 x 128.  Prefill sizes keep the tiles chosen above (128 or 256 columns).
+        if (M <= 1024) {
+            const int64_t b32 = ((M + 31) / 32) * ((N + 127) / 128);
+            if (b32 > 512) { mt = 2; wn = 4; wk = 2; cp = 4; }
+            else { mt = 1; wn = 4; wk = 2; cp = 16; }
+            pick = -1;
+        }
+    }
+    if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group) && !(silu && (f_wn & 1)) &&
+        !(rope && f_wn != 4 && f_wn != 8)) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
     }
     pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
@@ -149,7 +161,10 @@ extern "C" {
 
 size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
-    return plan_workspace(make_plan(M, N, K, granularity == QL_PER_GROUP));
+    // (the qkv entry points with the RoPE epilogue may plan differently: cover both)
+    const size_t a = plan_workspace(make_plan(M, N, K, granularity == QL_PER_GROUP));
+    const size_t b = (N % 128 == 0) ? plan_workspace(make_plan(M, N, K, granularity == QL_PER_GROUP, false, true)) : 0;
+    return a > b ? a : b;
 }
 
 size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int granularity) {
@@ -159,7 +174,7 @@ size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int gran
     size_t need = 0;
     for (int64_t m = 32;; m += 32) {
         const int64_t mm = m < max_M ? m : max_M;
-        const size_t b = plan_workspace(make_plan(mm, N, K, granularity == QL_PER_GROUP));
+        const size_t b = ql_gemm_workspace_bytes(mm, N, K, granularity);
         if (b > need) need = b;
         if (mm == max_M) break;
     }
@@ -180,19 +195,35 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
     return QL_OK;
 }
 
+static int check_rope(const char* fn, const RopeArgs* r, int64_t M, int64_t N) {
+    if (!r) return QL_OK;
+    if (r->Hq <= 0 || r->Hkv <= 0 || (M > 0 && (!r->positions || !r->cos_sin || !r->q_out)) ||
+        (r->slot_mapping && (!r->k_cache || !r->v_cache))) {
+        set_error("%s: bad rope argument", fn);
+        return QL_EINVAL;
+    }
+    if (N != (int64_t)(r->Hq + 2 * r->Hkv) * 128) {
+        set_error("%s: N=%lld is not (Hq + 2 Hkv) * 128 = %lld", fn, (long long)N, (long long)(r->Hq + 2 * r->Hkv) * 128);
+        return QL_ESHAPE;
+    }
+    return QL_OK;
+}
+
 static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, const void* x, const void* qw,
                       const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+                      void* workspace, size_t workspace_bytes, void* stream, const RopeArgs* rope = nullptr) {
     const bool tiled = (wdtype & QL_TILED) != 0;
     wdtype &= ~QL_TILED;
     if ((wdtype != QL_INT8 && wdtype != QL_FP8) || granularity < QL_PER_ROW || granularity > QL_PER_GROUP ||
-        (M > 0 && (!x || !y)) || !qw || !sw) {
+        (M > 0 && (!x || (!y && !rope))) || !qw || !sw) {
         set_error("%s: bad argument (wdtype=%d granularity=%d)", fn, wdtype, granularity);
         return QL_EINVAL;
     }
     int rc = check_common(fn, M, N, K);
     if (rc) return rc;
     if (silu && N % 64) { set_error("%s: N=%lld must be a multiple of 64 (32-row gate/up strips)", fn, (long long)N); return QL_ESHAPE; }
+    rc = check_rope(fn, rope, M, N);
+    if (rc) return rc;
     const bool grp = granularity == QL_PER_GROUP;
     if (grp) {
         const bool ok = group >= 32 && group % 32 == 0 && K % group == 0;   // the kernels fold a group's sum at 32-k steps
@@ -207,7 +238,8 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     p.bias_after_round = granularity == QL_PER_ROW ? 0 : 1;
     p.silu = silu ? 1 : 0;
     p.wtiled = tiled ? 1 : 0;
-    const Plan pl = make_plan(M, N, K, grp, silu);
+    if (rope) { p.rope_on = 1; p.rope = *rope; }
+    const Plan pl = make_plan(M, N, K, grp, silu, rope != nullptr);
     kern_t k;
     if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp);
     else k = grp ? pick_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp);
@@ -216,16 +248,18 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
 
 static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const float* sx, const void* qw,
                      const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     size_t workspace_bytes, void* stream, const RopeArgs* rope = nullptr) {
     const bool tiled = (dtype & QL_TILED) != 0;
     dtype &= ~QL_TILED;
-    if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || !sx || !y)) || !qw || !sw) {
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || !sx || (!y && !rope))) || !qw || !sw) {
         set_error("%s: bad argument (dtype=%d)", fn, dtype);
         return QL_EINVAL;
     }
     int rc = check_common(fn, M, N, K);
     if (rc) return rc;
     if (silu && N % 64) { set_error("%s: N=%lld must be a multiple of 64 (32-row gate/up strips)", fn, (long long)N); return QL_ESHAPE; }
+    rc = check_rope(fn, rope, M, N);
+    if (rc) return rc;
     if (M == 0) return QL_OK;
     GemmParams p{};
     p.x = (const unsigned char*)qx; p.w = (const unsigned char*)qw; p.sw = sw; p.sx = sx;
@@ -233,7 +267,8 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = 0; p.sw_stride = 1; p.bias_after_round = 0;
     p.silu = silu ? 1 : 0;
     p.wtiled = tiled ? 1 : 0;
-    const Plan pl = make_plan(M, N, K, false, silu);
+    if (rope) { p.rope_on = 1; p.rope = *rope; }
+    const Plan pl = make_plan(M, N, K, false, silu, rope != nullptr);
     kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
@@ -276,6 +311,38 @@ int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x, const void* q
 int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
     return gemm_w8a8("ql_gemm_w8a8", false, dtype, qx, sx, qw, sw, bias, y, M, N, K, workspace, workspace_bytes, stream);
+}
+
+static RopeArgs rope_args(const int64_t* positions, const float* cos_sin, const void* q_norm_w, const void* k_norm_w,
+                          float eps, void* q_out, void* k_out, void* v_out, void* k_cache, void* v_cache,
+                          const int* slot_mapping, int Hq, int Hkv) {
+    return RopeArgs{positions, cos_sin, (const unsigned short*)q_norm_w, (const unsigned short*)k_norm_w,
+                    (unsigned short*)q_out, (unsigned short*)k_out, (unsigned short*)v_out, (unsigned short*)k_cache,
+                    (unsigned short*)v_cache, slot_mapping, eps, Hq, Hkv};
+}
+
+int ql_gemm_w8a16_rope(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
+                       int64_t M, int64_t N, int64_t K, int group, const int64_t* positions, const float* cos_sin,
+                       const void* q_norm_w, const void* k_norm_w, float eps, void* q_out, void* k_out, void* v_out,
+                       void* k_cache, void* v_cache, const int* slot_mapping, int Hq, int Hkv, int head_dim,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (head_dim != 128) { set_error("ql_gemm_w8a16_rope: head_dim=%d (only 128 is built)", head_dim); return QL_ESHAPE; }
+    const RopeArgs r = rope_args(positions, cos_sin, q_norm_w, k_norm_w, eps, q_out, k_out, v_out, k_cache, v_cache,
+                                 slot_mapping, Hq, Hkv);
+    return gemm_w8a16("ql_gemm_w8a16_rope", false, wdtype, granularity, x, qw, sw, bias, nullptr, M, N, K, group,
+                      workspace, workspace_bytes, stream, &r);
+}
+
+int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
+                      int64_t M, int64_t N, int64_t K, const int64_t* positions, const float* cos_sin,
+                      const void* q_norm_w, const void* k_norm_w, float eps, void* q_out, void* k_out, void* v_out,
+                      void* k_cache, void* v_cache, const int* slot_mapping, int Hq, int Hkv, int head_dim,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (head_dim != 128) { set_error("ql_gemm_w8a8_rope: head_dim=%d (only 128 is built)", head_dim); return QL_ESHAPE; }
+    const RopeArgs r = rope_args(positions, cos_sin, q_norm_w, k_norm_w, eps, q_out, k_out, v_out, k_cache, v_cache,
+                                 slot_mapping, Hq, Hkv);
+    return gemm_w8a8("ql_gemm_w8a8_rope", false, dtype, qx, sx, qw, sw, bias, nullptr, M, N, K, workspace, workspace_bytes,
+                     stream, &r);
 }
 
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,

@@ -28,6 +28,7 @@
 //     co-residency requirement).  Results are bit-reproducible run to run.
 #pragma once
 #include "ql_common.h"
+#include "ql_rope.h"
 #include <type_traits>
 
 namespace ql {
@@ -54,6 +55,8 @@ struct GemmParams {
     int silu;                    // 1: weight rows alternate 32-row strips of gate and up; y[M, N/2] = silu(gate) * up
     int swz_gn;                  // 0, or the number of XCD groups along N (1, 2, 4, 8) of the XCD-aware tile order
     int wtiled;                  // 1: w is stored as [N/32 strips][K/32 steps][64 lanes][16 bytes] (see ql_tile_weight)
+    int rope_on;                 // 1: qkv projection: y is not stored; q/k norm + RoPE + KV store run in the epilogue
+    RopeArgs rope;
 };
 
 typedef void (*kern_t)(const GemmParams);
@@ -124,7 +127,11 @@ struct Cfg {
     static constexpr int XALL = (DB ? 2 : 1) * XBYTES;
     static constexpr int PAIR = (WN >= 2) ? WK * (WN / 2) * MT * 16 * 64 * 2 : 0;   // gate/up exchange of the SiLU epilogue
     static constexpr int LDS0 = (XALL > RED) ? XALL : RED;
-    static constexpr int LDS = (LDS0 > PAIR) ? LDS0 : PAIR;
+    static constexpr int LDS1 = (LDS0 > PAIR) ? LDS0 : PAIR;
+    // qkv epilogue (tiles whose 128 or 256 columns are whole heads): the bf16 output tile, rows padded by 16 bytes
+    static constexpr int ROPE_RS = BN + 8;                        // elements per row of that image
+    static constexpr int ROPE = (WN == 4 || WN == 8) ? BM * ROPE_RS * 2 : 0;
+    static constexpr int LDS = (LDS1 > ROPE) ? LDS1 : ROPE;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(NP >= 1 && (BM * CPR) % NT == 0, "staging must tile the block");
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -519,6 +526,33 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
                 else pair(FalseT{});
             }
             return;
+        }
+        if constexpr (WN == 4 || WN == 8) {
+            if (p.rope_on) {
+                // qkv projection with the q/k norm + RoPE + KV-cache store in the epilogue: the tile's columns are
+                // whole 128-wide heads (host: N % 128 == 0), so the bf16 outputs go to an LDS image instead of y and
+                // eight lanes per (row, head) then run exactly the arithmetic of the stand-alone operator on them.
+                __syncthreads();                              // every wave is done with the x tile / reduce area
+                unsigned short* img = (unsigned short*)smem;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < RN; ++rr) {
+                        const int r = R0 + rr;
+                        const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);
+                        img[(rowc + 4 * lh) * C::ROPE_RS + wn * 32 + l31] = __builtin_bit_cast(unsigned short, outv(i, r, rowc));
+                    }
+                __syncthreads();
+                constexpr int HPT = C::BN / 128;              // heads per tile
+                const int head0 = (int)(bx * HPT);
+                for (int idx = tid; idx < C::BM * HPT * 8; idx += C::NT) {
+                    const int s8 = (idx & 7) * 8, hh = (idx >> 3) % HPT, row = (idx >> 3) / HPT;
+                    if (m0 + row >= p.M) break;               // (rows ascend with idx; whole 8-lane groups leave together)
+                    const unsigned short* src = img + row * C::ROPE_RS + hh * 128 + s8;
+                    rope_store_piece(*(const u16x8*)src, *(const u16x8*)(src + 64), m0 + row, head0 + hh, s8, p.rope);
+                }
+                return;
+            }
         }
         if (!nvalid) return;
         const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.N + (unsigned)n;   // within the block's rows

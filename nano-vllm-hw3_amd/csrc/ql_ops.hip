@@ -3,6 +3,7 @@
 // KV-cache store, SiLU*mul, and single-token (decode) attention over a paged KV cache.
 // All are HBM/L2-bound: 16-byte accesses per lane, f32 math, bf16 storage.
 #include "ql_common.h"
+#include "ql_rope.h"
 
 namespace ql {
 
@@ -30,12 +31,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
     const size_t row = blockIdx.x;
     const int nvec = H >> 3;
     float v[NV][8];
+    u16x8 ww[NV];     // norm weights: requested with the row, so their latency is not paid behind the reduction
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < nvec) {
             const u16x8 a = *(const u16x8*)(x + row * H + c * 8);
+            ww[j] = *(const u16x8*)(w + c * 8);
             if (res) {
                 const u16x8 b = *(const u16x8*)(res + row * H + c * 8);
                 u16x8 r;
@@ -63,11 +66,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
     for (int j = 0; j < NV; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < nvec) {
-            const u16x8 ww = *(const u16x8*)(w + c * 8);
             u16x8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                o[k] = f32_to_bf16_bits(round_to_bf16(v[j][k] * inv) * bf16_bits_to_f32(ww[k]));
+                o[k] = f32_to_bf16_bits(round_to_bf16(v[j][k] * inv) * bf16_bits_to_f32(ww[j][k]));
             if constexpr (QDT < 0) {
                 *(u16x8*)(out + row * H + c * 8) = o;
             } else {
@@ -125,76 +127,16 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const unsigned short* __r
 }
 
 // ---- per-head RMSNorm (optional) + rotate-half RoPE on q and k, and K/V scatter into the paged cache
-// Eight lanes per (token, head); head_dim = 128: lane s holds elements 8s .. 8s+7 and 64+8s .. 64+8s+7
-// (two 16-byte accesses), which are exactly the (x1, x2) pairs the rotation mixes, so only the
-// sum of squares of the norm crosses lanes (three shuffle steps inside the 8-lane group).
-__global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
-    const unsigned short* __restrict__ qkv, const int64_t* __restrict__ positions,
-    const float* __restrict__ cos_sin, const unsigned short* __restrict__ qw,
-    const unsigned short* __restrict__ kw, float eps, unsigned short* __restrict__ q_out,
-    unsigned short* __restrict__ k_out, unsigned short* __restrict__ v_out,
-    unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
-    const int* __restrict__ slot_mapping, int T, int Hq, int Hkv) {
-    const int heads = Hq + 2 * Hkv;
+// Eight lanes per (token, head); the arithmetic lives in ql_rope.h (shared with the fused qkv GEMM epilogue).
+__global__ __launch_bounds__(256) void qknorm_rope_store_kernel(const unsigned short* __restrict__ qkv, int T, const RopeArgs r) {
+    const int heads = r.Hq + 2 * r.Hkv;
     const int64_t pair = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;      // (token, head) index
     const int s8 = (threadIdx.x & 7) * 8;
     if (pair >= (int64_t)T * heads) return;
     const int t = (int)(pair / heads), h = (int)(pair % heads);
     const unsigned short* src = qkv + ((size_t)t * heads + h) * 128 + s8;
     const u16x8 a1 = *(const u16x8*)src, a2 = *(const u16x8*)(src + 64);
-    const int slot = slot_mapping ? slot_mapping[t] : -1;
-    if (h >= Hq + Hkv) {   // V: copy only
-        const size_t hv = h - Hq - Hkv;
-        if (v_out) {
-            *(u16x8*)(v_out + ((size_t)t * Hkv + hv) * 128 + s8) = a1;
-            *(u16x8*)(v_out + ((size_t)t * Hkv + hv) * 128 + 64 + s8) = a2;
-        }
-        if (slot >= 0) {
-            *(u16x8*)(v_cache + ((size_t)slot * Hkv + hv) * 128 + s8) = a1;
-            *(u16x8*)(v_cache + ((size_t)slot * Hkv + hv) * 128 + 64 + s8) = a2;
-        }
-        return;
-    }
-    float x1[8], x2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { x1[j] = bf16_bits_to_f32(a1[j]); x2[j] = bf16_bits_to_f32(a2[j]); }
-    const bool is_q = h < Hq;
-    const unsigned short* nw = is_q ? qw : kw;
-    if (nw) {
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss += x1[j] * x1[j] + x2[j] * x2[j];
-        ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
-        const float inv = rsqrtf(ss * (1.f / 128.f) + eps);
-        const u16x8 w1 = *(const u16x8*)(nw + s8), w2 = *(const u16x8*)(nw + 64 + s8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            x1[j] = round_to_bf16(round_to_bf16(x1[j] * inv) * bf16_bits_to_f32(w1[j]));
-            x2[j] = round_to_bf16(round_to_bf16(x2[j] * inv) * bf16_bits_to_f32(w2[j]));
-        }
-    }
-    const float* cs = cos_sin + positions[t] * 128 + s8;
-    u16x8 y1, y2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float c = cs[j], sn = cs[64 + j];
-        y1[j] = f32_to_bf16_bits(x1[j] * c - x2[j] * sn);
-        y2[j] = f32_to_bf16_bits(x2[j] * c + x1[j] * sn);
-    }
-    if (is_q) {
-        *(u16x8*)(q_out + ((size_t)t * Hq + h) * 128 + s8) = y1;
-        *(u16x8*)(q_out + ((size_t)t * Hq + h) * 128 + 64 + s8) = y2;
-    } else {
-        const size_t hk = h - Hq;
-        if (k_out) {
-            *(u16x8*)(k_out + ((size_t)t * Hkv + hk) * 128 + s8) = y1;
-            *(u16x8*)(k_out + ((size_t)t * Hkv + hk) * 128 + 64 + s8) = y2;
-        }
-        if (slot >= 0) {
-            *(u16x8*)(k_cache + ((size_t)slot * Hkv + hk) * 128 + s8) = y1;
-            *(u16x8*)(k_cache + ((size_t)slot * Hkv + hk) * 128 + 64 + s8) = y2;
-        }
-    }
+    rope_store_piece(a1, a2, t, h, s8, r);
 }
 
 // ---- decode attention over a paged KV cache ------------------------------------------------------
@@ -453,11 +395,11 @@ int ql_qknorm_rope_store(const void* qkv, const int64_t* positions, const float*
     const int64_t pairs = T * (Hq + 2 * Hkv);                 // 8 lanes each, 32 per 256-thread block
     const int64_t blocks = (pairs + 31) / 32;
     if (blocks > 0x7FFFFFFF) { set_error("ql_qknorm_rope_store: too many tokens"); return QL_ESHAPE; }
+    RopeArgs r{positions, cos_sin, (const unsigned short*)q_norm_w, (const unsigned short*)k_norm_w, (unsigned short*)q_out,
+               (unsigned short*)k_out, (unsigned short*)v_out, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping,
+               eps, Hq, Hkv};
     hipLaunchKernelGGL(qknorm_rope_store_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                       (const unsigned short*)qkv, positions, cos_sin, (const unsigned short*)q_norm_w,
-                       (const unsigned short*)k_norm_w, eps, (unsigned short*)q_out, (unsigned short*)k_out,
-                       (unsigned short*)v_out, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, (int)T,
-                       Hq, Hkv);
+                       (const unsigned short*)qkv, (int)T, r);
     QL_CHECK_LAUNCH("ql_qknorm_rope_store");
     return QL_OK;
 }

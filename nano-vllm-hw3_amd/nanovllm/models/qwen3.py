@@ -29,6 +29,11 @@ class AttnContext:
 
 _CTX = AttnContext()
 
+# the qkv GEMM of a quantized model carries the q/k norm + RoPE + KV store in its epilogue (bit-identical to the
+# separate operator on the same tile; NANOVLLM_NO_QKV_ROPE=1 keeps the two launches, for A/B measurements)
+import os as _os
+FUSE_QKV_ROPE = _os.environ.get("NANOVLLM_NO_QKV_ROPE", "") == ""
+
 
 def set_context(ctx: AttnContext):
     global _CTX
@@ -118,12 +123,19 @@ class Qwen3Attention(nn.Module):
 
     def forward(self, positions, hidden_states, quantized=None):
         ctx = get_context()
-        qkv = self.qkv_proj(hidden_states) if quantized is None else self.qkv_proj.forward_quantized(*quantized)
         qw = self.q_norm.weight if not self.qkv_bias else None
         kw = self.k_norm.weight if not self.qkv_bias else None
-        q, k, v = ops.qknorm_rope_store(qkv, positions, self.cos_sin, qw, kw, self.eps, self.num_heads,
-                                        self.num_kv_heads, self.head_dim, self.k_cache, self.v_cache,
-                                        ctx.slot_mapping, want_kv=ctx.is_prefill)
+        if FUSE_QKV_ROPE and hasattr(self.qkv_proj, "qw") and self.head_dim == 128 and self.qkv_proj.qw.shape[1] % 32 == 0:
+            # quantized qkv projection: q/k norm + RoPE + KV-cache store run in the GEMM's epilogue (one launch)
+            from nanovllm.utils.quantization import qkv_rope_matmul
+            q, k, v = qkv_rope_matmul(self.qkv_proj, hidden_states, positions, self.cos_sin, qw, kw, self.eps,
+                                      self.num_heads, self.num_kv_heads, self.head_dim, self.k_cache, self.v_cache,
+                                      ctx.slot_mapping, want_kv=ctx.is_prefill, quantized=quantized)
+        else:
+            qkv = self.qkv_proj(hidden_states) if quantized is None else self.qkv_proj.forward_quantized(*quantized)
+            q, k, v = ops.qknorm_rope_store(qkv, positions, self.cos_sin, qw, kw, self.eps, self.num_heads,
+                                            self.num_kv_heads, self.head_dim, self.k_cache, self.v_cache,
+                                            ctx.slot_mapping, want_kv=ctx.is_prefill)
         if ctx.is_prefill:
             cu_dev = ctx.cu_seqlens_dev
             if cu_dev is None:

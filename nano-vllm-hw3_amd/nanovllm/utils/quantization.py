@@ -225,6 +225,58 @@ def per_row_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
     return w8a8_matmul(qx, sx, qw, sw, bias, dtype, None if out is not None else y_shape, silu, out)
 
 
+@torch.no_grad()
+def qkv_rope_matmul(mod, x, positions, cos_sin, q_norm_w, k_norm_w, eps, num_heads, num_kv_heads, head_dim,
+                    k_cache=None, v_cache=None, slot_mapping=None, want_kv=True, quantized=None):
+    """The qkv projection of a quantized module with q/k norm + RoPE + KV-cache store in the GEMM epilogue
+    (qwen3.py:80-88 + attention.py:52-58 of the reference in one launch): returns (q [T,Hq,D], k, v) like
+    ops.qknorm_rope_store and never materialises the [T, N] projection.  ``quantized`` = (qx, sx) for a W8A8
+    module whose input was quantized by the preceding norm."""
+    lib = Q.load()
+    dtype = mod.dtype
+    N, K = mod.qw.shape
+    dev = mod.qw.device
+    w8a8 = isinstance(mod, QLinear) and not mod.weight_only
+    if w8a8:
+        if quantized is None:
+            x2 = x.reshape(-1, x.shape[-1])
+            qx, sx = per_row_quant(x2.contiguous(), dtype)
+        else:
+            qx, sx = quantized
+        Q.require_cuda(qx, dtype, "qx")
+        T = qx.shape[0]
+    else:
+        x2 = Q.require_cuda(x.reshape(-1, x.shape[-1]), torch.bfloat16, "x")
+        T = x2.shape[0]
+    q = torch.empty((T, num_heads, head_dim), dtype=torch.bfloat16, device=dev)
+    k = torch.empty((T, num_kv_heads, head_dim), dtype=torch.bfloat16, device=dev) if want_kv else None
+    v = torch.empty((T, num_kv_heads, head_dim), dtype=torch.bfloat16, device=dev) if want_kv else None
+    use_cache = slot_mapping is not None and k_cache is not None and k_cache.numel() > 0
+    bias = mod._bias_for_rank()
+    tail = (positions.data_ptr(), cos_sin.data_ptr(), q_norm_w.data_ptr() if q_norm_w is not None else None,
+            k_norm_w.data_ptr() if k_norm_w is not None else None, eps, q.data_ptr(),
+            k.data_ptr() if want_kv else None, v.data_ptr() if want_kv else None,
+            k_cache.data_ptr() if use_cache else None, v_cache.data_ptr() if use_cache else None,
+            slot_mapping.data_ptr() if use_cache else None, num_heads, num_kv_heads, head_dim)
+    if w8a8:
+        ws_ptr, ws_len = Q.workspace.get(dev, lib.ql_gemm_workspace_bytes(T, N, K, Q.QL_PER_ROW))
+        Q.check(lib.ql_gemm_w8a8_rope(_wcode(mod.qw, dtype), qx.data_ptr(), sx.data_ptr(), mod.qw.data_ptr(),
+                                      mod.sw.data_ptr(), bias.data_ptr() if bias is not None else None, T, N, K, *tail,
+                                      ws_ptr, ws_len, Q.stream_ptr(dev)))
+    else:
+        if isinstance(mod, QGroupLinear):
+            gran, group, sw = Q.QL_PER_GROUP, mod.group_size, mod.sw
+        elif isinstance(mod, QTensorLinear):
+            gran, group, sw = Q.QL_PER_TENSOR, 0, mod._sw32
+        else:
+            gran, group, sw = Q.QL_PER_ROW, 0, mod.sw
+        ws_ptr, ws_len = Q.workspace.get(dev, lib.ql_gemm_workspace_bytes(T, N, K, gran))
+        Q.check(lib.ql_gemm_w8a16_rope(_wcode(mod.qw, dtype), gran, x2.data_ptr(), mod.qw.data_ptr(), sw.data_ptr(),
+                                       bias.data_ptr() if bias is not None else None, T, N, K, group, *tail,
+                                       ws_ptr, ws_len, Q.stream_ptr(dev)))
+    return q, k, v
+
+
 def interleave_gate_up(t: torch.Tensor):
     """Rows [gate (I) | up (I)] -> 32-row strips alternating gate, up: the weight arrangement of the
     fused SiLU epilogue (row 64*s + j = gate row 32*s + j for j < 32, up row 32*s + j - 32 otherwise)."""

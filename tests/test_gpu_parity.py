@@ -352,6 +352,94 @@ def test_fused_silu_epilogue_bit_identical(NQ, tile):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+def _rope_setup(M, Hq, Hkv, K, seed, slots_free=4096):
+    from nanovllm.models.qwen3 import build_cos_sin
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    N = (Hq + 2 * Hkv) * 128
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = (torch.randn(N, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    qn = (1 + 0.2 * torch.randn(128, device="cuda", generator=g)).to(torch.bfloat16)
+    kn = (1 + 0.2 * torch.randn(128, device="cuda", generator=g)).to(torch.bfloat16)
+    cs = build_cos_sin(128, 4096, 1e6, "cuda")
+    pos = torch.randint(0, 4096, (M,), device="cuda", generator=g)
+    slots = torch.randperm(slots_free, device="cuda", generator=g)[:M].to(torch.int32)
+    if M > 3:
+        slots[3] = -1                                   # a padded row: nothing is stored for it
+    return x, w, bias, qn, kn, cs, pos, slots
+
+
+def _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, want_kv, quantized=None):
+    """(fused, unfused) results: q, k, v and the two caches."""
+    from nanovllm import ops
+    outs = []
+    for fused in (True, False):
+        kc = torch.zeros(16, 256, Hkv, 128, device="cuda", dtype=torch.bfloat16)
+        vc = torch.zeros_like(kc)
+        if fused:
+            q, k, v = NQ.qkv_rope_matmul(mod, x, pos, cs, qn, kn, 1e-6, Hq, Hkv, 128, kc, vc, slots, want_kv, quantized)
+        else:
+            qkv = mod(x) if quantized is None else mod.forward_quantized(*quantized)
+            q, k, v = ops.qknorm_rope_store(qkv, pos, cs, qn, kn, 1e-6, Hq, Hkv, 128, kc, vc, slots, want_kv)
+        torch.cuda.synchronize()
+        outs.append((q, k, v, kc, vc))
+    return outs
+
+
+@pytest.mark.parametrize("tile", [t for t in TILES if t[1] in (4, 8)])
+@pytest.mark.parametrize("split", [1, 3])
+def test_qkv_rope_epilogue_bit_identical(NQ, tile, split):
+    """qkv GEMM with the q/k norm + RoPE + KV-cache store in its epilogue == the plain GEMM (same tile, same split)
+    followed by the stand-alone operator, bit for bit: q, k, v and both caches; every arithmetic variant, every tile
+    whose columns are whole heads, M tails, a padded (-1) slot, with and without the norm weights and a bias."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    M, Hq, Hkv, K = 70, 2, 1, 1184
+    x, w, bias, qn, kn, cs, pos, slots = _rope_setup(M, Hq, Hkv, K, 3)
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], split) == 0
+        mods = [NQ.QLinear(torch.int8, w, None, weight_only=True), NQ.QLinear(torch.float8_e4m3fn, w, bias, weight_only=True),
+                NQ.QLinear(torch.int8, w, bias), NQ.QLinear(torch.float8_e4m3fn, w, None), NQ.QTensorLinear(torch.int8, w, None)]
+        if tile[0] <= 4:
+            mods.append(NQ.QGroupLinear(torch.int8, w[:, :1152].contiguous(), None, 128))
+        for mi, mod in enumerate(mods):
+            mod.tile()
+            xx = x if mod.qw.shape[1] == K else x[:, :1152].contiguous()
+            for norms in ((qn, kn), (None, None)):
+                for want_kv in (True, False):
+                    a, b = _rope_both_ways(NQ, mod, xx, norms[0], norms[1], cs, pos, slots, Hq, Hkv, want_kv)
+                    for ta, tb, nm in zip(a, b, ("q", "k", "v", "k_cache", "v_cache")):
+                        assert (ta is None) == (tb is None)
+                        if ta is not None:
+                            assert torch.equal(ta, tb), (mi, nm, tile, split, want_kv)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 130, 256, 700, 2048])
+def test_qkv_rope_full_size_own_tiles(NQ, M):
+    """Qwen3-0.6B qkv shape with the library's own tile choice for each route.  int8 W8A8 accumulates exactly, so the
+    fused route must equal the unfused one bit for bit whatever tiles the two pick (also with the activations
+    quantized by the preceding norm); the float variants are compared at the GEMM's rounding level."""
+    from nanovllm import ops
+    Hq, Hkv, K = 16, 8, 1024
+    x, w, bias, qn, kn, cs, pos, slots = _rope_setup(M, Hq, Hkv, K, M)
+    mod = NQ.QLinear(torch.int8, w, None).tile()
+    a, b = _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, M > 256)
+    for ta, tb in zip(a, b):
+        assert (ta is None) == (tb is None) and (ta is None or torch.equal(ta, tb))
+    qx, sx = NQ.per_row_quant(x, torch.int8)
+    a, b = _rope_both_ways(NQ, mod, None, qn, kn, cs, pos, slots, Hq, Hkv, False, quantized=(qx, sx))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    for mk in (lambda: NQ.QLinear(torch.int8, w, None, weight_only=True), lambda: NQ.QGroupLinear(torch.float8_e4m3fn, w, None, 128)):
+        mod = mk().tile()
+        a, b = _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, False)
+        for ta, tb in ((a[0], b[0]), (a[3], b[3]), (a[4], b[4])):
+            d = (ta.float() - tb.float()).abs()
+            assert (d <= 2.0 ** -5 * tb.float().abs() + 3e-2).all()
+            assert (ta == tb).float().mean() > 0.9
+
+
 @pytest.mark.parametrize("M", [1, 16, 33, 130, 256, 2048])
 def test_fused_silu_full_size_and_module(NQ, M):
     """Qwen3-0.6B gate/up shape through the module API with the library's own tile choice: int8 W8A8 is
