@@ -190,7 +190,9 @@ int ql_silu_mul(const void* x_bf16, void* out_bf16, int64_t T, int64_t I, void* 
  * split qkv[T, (Hq+2Hkv)*128], per-head RMSNorm of q and k (weights may be NULL = no norm),
  * rotate-half RoPE from cos_sin[pos, 0:64 | 64:128] (f32), q -> q_out[T,Hq,128]; k, v -> k_out/v_out
  * (optional, contiguous, for prefill attention) and scattered to k_cache/v_cache at row
- * slot_mapping[t] (skipped for -1 or a NULL slot_mapping).  head_dim must be 128. */
+ * slot_mapping[t] (skipped for -1 or a NULL slot_mapping).  head_dim must be 128.  positions may be NULL:
+ * cos_sin then holds one row per token, [T, 128], already gathered (one gather per step serves every layer and
+ * takes the position -> table-row dependency out of each call). */
 int ql_qknorm_rope_store(const void* qkv_bf16, const int64_t* positions, const float* cos_sin,
                          const void* q_norm_w, const void* k_norm_w, float eps, void* q_out, void* k_out,
                          void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int64_t T,

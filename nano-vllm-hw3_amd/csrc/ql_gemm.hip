@@ -18,6 +18,13 @@ static bool tile_built(int mt, int wn, int wk, int cp, bool group) {
     return false;
 }
 
+static bool rope_tile_built(int mt, int wn, int wk, int cp) {
+#define QL_ROW(MT_, WN_, WK_, CP_, DB_) if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) return true;
+    QL_TILE_LIST_ROPE(QL_ROW)
+#undef QL_ROW
+    return false;
+}
+
 struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; };
 
 static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false, bool rope = false) {
@@ -75,7 +82,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
         }
     }
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group) && !(silu && (f_wn & 1)) &&
-        !(rope && f_wn != 4 && f_wn != 8)) {
+        !(rope && !rope_tile_built(f_mt, f_wn, f_wk, f_cp))) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
     }
     pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
@@ -197,7 +204,7 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
 
 static int check_rope(const char* fn, const RopeArgs* r, int64_t M, int64_t N) {
     if (!r) return QL_OK;
-    if (r->Hq <= 0 || r->Hkv <= 0 || (M > 0 && (!r->positions || !r->cos_sin || !r->q_out)) ||
+    if (r->Hq <= 0 || r->Hkv <= 0 || (M > 0 && (!r->cos_sin || !r->q_out)) ||
         (r->slot_mapping && (!r->k_cache || !r->v_cache))) {
         set_error("%s: bad rope argument", fn);
         return QL_EINVAL;
@@ -241,8 +248,9 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     if (rope) { p.rope_on = 1; p.rope = *rope; }
     const Plan pl = make_plan(M, N, K, grp, silu, rope != nullptr);
     kern_t k;
-    if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp);
-    else k = grp ? pick_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp);
+    const bool rp = rope != nullptr;
+    if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
+    else k = grp ? pick_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
 
@@ -269,7 +277,7 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     p.wtiled = tiled ? 1 : 0;
     if (rope) { p.rope_on = 1; p.rope = *rope; }
     const Plan pl = make_plan(M, N, K, false, silu, rope != nullptr);
-    kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp);
+    kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
 

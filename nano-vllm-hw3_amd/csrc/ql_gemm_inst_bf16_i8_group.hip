@@ -2,5 +2,5 @@
 // the other variants; see ql_gemm_kernel.h).
 #include "ql_gemm_kernel.h"
 namespace ql {
-kern_t pick_bf16_i8_group(int mt, int wn, int wk, int cp) { return pick_kernel_impl<ACT_BF16, false, true>(mt, wn, wk, cp); }
+kern_t pick_bf16_i8_group(int mt, int wn, int wk, int cp, bool rope) { return pick_kernel_impl<ACT_BF16, false, true>(mt, wn, wk, cp, rope); }
 }  // namespace ql

@@ -2,5 +2,5 @@
 // the other variants; see ql_gemm_kernel.h).
 #include "ql_gemm_kernel.h"
 namespace ql {
-kern_t pick_fp8_fp8(int mt, int wn, int wk, int cp) { return pick_kernel_impl<ACT_FP8, true, false>(mt, wn, wk, cp); }
+kern_t pick_fp8_fp8(int mt, int wn, int wk, int cp, bool rope) { return pick_kernel_impl<ACT_FP8, true, false>(mt, wn, wk, cp, rope); }
 }  // namespace ql

@@ -55,7 +55,7 @@ struct GemmParams {
     int silu;                    // 1: weight rows alternate 32-row strips of gate and up; y[M, N/2] = silu(gate) * up
     int swz_gn;                  // 0, or the number of XCD groups along N (1, 2, 4, 8) of the XCD-aware tile order
     int wtiled;                  // 1: w is stored as [N/32 strips][K/32 steps][64 lanes][16 bytes] (see ql_tile_weight)
-    int rope_on;                 // 1: qkv projection: y is not stored; q/k norm + RoPE + KV store run in the epilogue
+    int rope_on;                 // 1 on the ROPE kernels (qkv projection: y is not stored; q/k norm + RoPE + KV store in the epilogue)
     RopeArgs rope;
 };
 
@@ -130,15 +130,17 @@ struct Cfg {
     static constexpr int LDS1 = (LDS0 > PAIR) ? LDS0 : PAIR;
     // qkv epilogue (tiles whose 128 or 256 columns are whole heads): the bf16 output tile, rows padded by 16 bytes
     static constexpr int ROPE_RS = BN + 8;                        // elements per row of that image
-    static constexpr int ROPE = (WN == 4 || WN == 8) ? BM * ROPE_RS * 2 : 0;
-    static constexpr int LDS = (LDS1 > ROPE) ? LDS1 : ROPE;
+    static constexpr int ROPE = BM * ROPE_RS * 2;
+    static constexpr int LDS = LDS1;
+    static constexpr int LDS_ROPE = (LDS1 > ROPE) ? LDS1 : ROPE;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(NP >= 1 && (BM * CPR) % NT == 0, "staging must tile the block");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP>
+template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP, bool ROPE = false>
 __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p) {
+    static_assert(!ROPE || WN == 4 || WN == 8, "the qkv epilogue needs whole 128-column heads per workgroup");
     using C = Cfg<ACT, MT, WN, WK, CP, DB>;
     constexpr bool INT = (ACT == ACT_I8);
     constexpr int RB = C::RB;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     using raw_t = typename std::conditional<INT, int, float>::type;
     using TrueT = std::integral_constant<bool, true>;
     using FalseT = std::integral_constant<bool, false>;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[C::LDS];   // base must be a multiple of 32 (address ^ 16 below)
+    __shared__ __attribute__((aligned(128))) unsigned char smem[ROPE ? C::LDS_ROPE : C::LDS];   // base must be a multiple of 32 (address ^ 16 below)
 
     // The kernel is VALU-issue-bound at decode sizes, so everything that is uniform per wave is kept
     // in scalar registers (the wave index is made provably uniform) and every per-lane address is
@@ -205,6 +207,19 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     const int a_g4 = ((((l31 / SWZ_RPB) & SWZ_MASK) ^ (ACT == ACT_BF16 ? 2 * lh : lh)) & SWZ_MASK) << 4;
     const int a_hi = (ACT == ACT_BF16 ? 2 * lh : lh) & ~SWZ_MASK;   // 0 unless a row has < 4 pieces (never)
     const int a_row = l31 * RB + (a_hi << 4);
+
+    // qkv epilogue: what the thread's first (row, head, piece) needs from memory (cache slot, cos/sin of the token's
+    // position, norm weights) is requested NOW, so that this chain of dependent reads is over long before the tail
+    // (only where one pass of the workgroup's threads covers the tile, i.e. the decode tiles: there the tail's
+    // latency is what counts; the large prefill tiles have no registers to spare and load at the tail)
+    constexpr bool ROPE_EARLY = ROPE && (C::BM * (C::BN / 128) * 8 <= C::NT);
+    RopePre rope_pre;
+    if constexpr (ROPE_EARLY) {
+        constexpr int HPT = C::BN / 128;
+        const int row = (tid >> 3) / HPT, hh = (tid >> 3) % HPT;
+        if (tid < C::BM * HPT * 8 && m0 + row < p.M)
+            rope_pre = rope_prefetch(m0 + row, (int)(bx * HPT) + hh, (tid & 7) * 8, p.rope);
+    }
 
     acc_t acc[MT];
     acc_t accg[GROUP ? MT : 1];
@@ -527,8 +542,8 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             }
             return;
         }
-        if constexpr (WN == 4 || WN == 8) {
-            if (p.rope_on) {
+        if constexpr (ROPE) {
+            {
                 // qkv projection with the q/k norm + RoPE + KV-cache store in the epilogue: the tile's columns are
                 // whole 128-wide heads (host: N % 128 == 0), so the bf16 outputs go to an LDS image instead of y and
                 // eight lanes per (row, head) then run exactly the arithmetic of the stand-alone operator on them.
@@ -549,7 +564,10 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
                     const int s8 = (idx & 7) * 8, hh = (idx >> 3) % HPT, row = (idx >> 3) / HPT;
                     if (m0 + row >= p.M) break;               // (rows ascend with idx; whole 8-lane groups leave together)
                     const unsigned short* src = img + row * C::ROPE_RS + hh * 128 + s8;
-                    rope_store_piece(*(const u16x8*)src, *(const u16x8*)(src + 64), m0 + row, head0 + hh, s8, p.rope);
+                    RopePre pre;
+                    if constexpr (ROPE_EARLY) pre = rope_pre;      // (one pass: idx == tid, and the row was valid at entry)
+                    else pre = rope_prefetch(m0 + row, head0 + hh, s8, p.rope);
+                    rope_store_piece(*(const u16x8*)src, *(const u16x8*)(src + 64), m0 + row, head0 + hh, s8, p.rope, pre);
                 }
                 return;
             }
@@ -601,10 +619,19 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(1, 4, 1, 32, false) X(1, 4, 2, 16, false) X(2, 4, 2, 16, false) X(1, 2, 4, 16, false) X(1, 1, 8, 8, false) \
     X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)
 #define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
+// tiles also built with the qkv (q/k norm + RoPE + KV store) epilogue: 128- or 256-column tiles
+#define QL_TILE_LIST_ROPE(X) X(1, 4, 2, 16, false) X(1, 4, 1, 4, true) X(2, 4, 2, 4, true) X(2, 4, 1, 4, true) X(4, 8, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these
 template <int ACT, bool FP8W, bool GROUP>
-kern_t pick_kernel_impl(int mt, int wn, int wk, int cp) {
+kern_t pick_kernel_impl(int mt, int wn, int wk, int cp, bool rope) {
+    if (rope) {
+#define QL_PICK(MT_, WN_, WK_, CP_, DB_) \
+        if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) return (kern_t)qgemm_kernel<ACT, FP8W, MT_, WN_, WK_, CP_, DB_, GROUP, true>;
+        QL_TILE_LIST_ROPE(QL_PICK)
+#undef QL_PICK
+        return nullptr;
+    }
 #define QL_PICK(MT_, WN_, WK_, CP_, DB_) \
     if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) return (kern_t)qgemm_kernel<ACT, FP8W, MT_, WN_, WK_, CP_, DB_, GROUP>;
     QL_TILE_LIST(QL_PICK)
@@ -619,11 +646,11 @@ int w8a16_dispatch(const char* fn, int wdtype, int granularity, const void* x, c
                    size_t workspace_bytes, void* stream);
 size_t w8a16_workspace_need(int64_t M, int64_t N, int64_t K, int granularity, size_t* ticket_bytes);
 
-kern_t pick_bf16_i8_row(int, int, int, int);
-kern_t pick_bf16_i8_group(int, int, int, int);
-kern_t pick_bf16_fp8_row(int, int, int, int);
-kern_t pick_bf16_fp8_group(int, int, int, int);
-kern_t pick_i8_i8(int, int, int, int);
-kern_t pick_fp8_fp8(int, int, int, int);
+kern_t pick_bf16_i8_row(int, int, int, int, bool rope = false);
+kern_t pick_bf16_i8_group(int, int, int, int, bool rope = false);
+kern_t pick_bf16_fp8_row(int, int, int, int, bool rope = false);
+kern_t pick_bf16_fp8_group(int, int, int, int, bool rope = false);
+kern_t pick_i8_i8(int, int, int, int, bool rope = false);
+kern_t pick_fp8_fp8(int, int, int, int, bool rope = false);
 
 }  // namespace ql

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(const unsigned s
     const int t = (int)(pair / heads), h = (int)(pair % heads);
     const unsigned short* src = qkv + ((size_t)t * heads + h) * 128 + s8;
     const u16x8 a1 = *(const u16x8*)src, a2 = *(const u16x8*)(src + 64);
-    rope_store_piece(a1, a2, t, h, s8, r);
+    rope_store_piece(a1, a2, t, h, s8, r, rope_prefetch(t, h, s8, r));
 }
 
 // ---- decode attention over a paged KV cache ------------------------------------------------------
@@ -385,7 +385,7 @@ int ql_silu_mul(const void* x, void* out, int64_t T, int64_t I, void* stream) {
 int ql_qknorm_rope_store(const void* qkv, const int64_t* positions, const float* cos_sin, const void* q_norm_w,
                          const void* k_norm_w, float eps, void* q_out, void* k_out, void* v_out, void* k_cache,
                          void* v_cache, const int* slot_mapping, int64_t T, int Hq, int Hkv, int head_dim, void* stream) {
-    if (T < 0 || Hq <= 0 || Hkv <= 0 || (T > 0 && (!qkv || !positions || !cos_sin || !q_out)) ||
+    if (T < 0 || Hq <= 0 || Hkv <= 0 || (T > 0 && (!qkv || !cos_sin || !q_out)) ||
         (slot_mapping && (!k_cache || !v_cache))) {
         set_error("ql_qknorm_rope_store: bad argument");
         return QL_EINVAL;

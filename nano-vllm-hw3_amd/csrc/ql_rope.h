@@ -10,8 +10,8 @@
 namespace ql {
 
 struct RopeArgs {
-    const int64_t* positions;       // [T]
-    const float* cos_sin;           // [max_pos, 128] f32: cos[0:64] | sin[64:128]
+    const int64_t* positions;       // [T], or null: cos_sin then holds one row per TOKEN, already gathered
+    const float* cos_sin;           // [max_pos, 128] f32: cos[0:64] | sin[64:128]   ([T, 128] when positions is null)
     const unsigned short* qw;       // [128] bf16 q-norm weight or null
     const unsigned short* kw;       // [128] bf16 k-norm weight or null
     unsigned short* q_out;          // [T, Hq, 128]
@@ -24,11 +24,39 @@ struct RopeArgs {
     int Hq, Hkv;
 };
 
+// What a (token, piece) needs from memory besides its own values: the cache slot, the cos/sin pieces of the token's
+// position and the norm weights.  Loading them is a chain of dependent reads (position -> table row), so a caller
+// with other work to do first (the GEMM) requests them early and keeps them in registers.
+struct RopePre {
+    float c[8], sn[8];
+    u16x8 w1, w2;
+    int slot;
+};
+
+__device__ __forceinline__ RopePre rope_prefetch(int t, int h, int s8, const RopeArgs& r) {
+    RopePre pre;
+    pre.slot = r.slot_mapping ? r.slot_mapping[t] : -1;
+    const bool is_v = h >= r.Hq + r.Hkv;
+    const unsigned short* nw = (h < r.Hq) ? r.qw : r.kw;
+    pre.w1 = pre.w2 = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (!is_v) {
+        if (nw) { pre.w1 = *(const u16x8*)(nw + s8); pre.w2 = *(const u16x8*)(nw + 64 + s8); }
+        const float* cs = r.cos_sin + (r.positions ? r.positions[t] : (int64_t)t) * 128 + s8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pre.c[j] = cs[j]; pre.sn[j] = cs[64 + j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pre.c[j] = 1.f; pre.sn[j] = 0.f; }
+    }
+    return pre;
+}
+
 // All eight lanes of the group must call this together (it shuffles); t = token, h = head index in
 // [0, Hq + 2 Hkv) (q heads, then k heads, then v heads), s8 = 8 * (lane & 7).
-__device__ __forceinline__ void rope_store_piece(const u16x8 a1, const u16x8 a2, int t, int h, int s8, const RopeArgs& r) {
+__device__ __forceinline__ void rope_store_piece(const u16x8 a1, const u16x8 a2, int t, int h, int s8, const RopeArgs& r,
+                                                 const RopePre& pre) {
     const int Hq = r.Hq, Hkv = r.Hkv;
-    const int slot = r.slot_mapping ? r.slot_mapping[t] : -1;
+    const int slot = pre.slot;
     if (h >= Hq + Hkv) {   // V: copy only
         const size_t hv = h - Hq - Hkv;
         if (r.v_out) {
@@ -52,18 +80,16 @@ __device__ __forceinline__ void rope_store_piece(const u16x8 a1, const u16x8 a2,
         for (int j = 0; j < 8; ++j) { ss = __builtin_fmaf(x1[j], x1[j], ss); ss = __builtin_fmaf(x2[j], x2[j], ss); }
         ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
         const float inv = rsqrtf(__builtin_fmaf(ss, 1.f / 128.f, r.eps));
-        const u16x8 w1 = *(const u16x8*)(nw + s8), w2 = *(const u16x8*)(nw + 64 + s8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            x1[j] = round_to_bf16(__fmul_rn(round_to_bf16(__fmul_rn(x1[j], inv)), bf16_bits_to_f32(w1[j])));
-            x2[j] = round_to_bf16(__fmul_rn(round_to_bf16(__fmul_rn(x2[j], inv)), bf16_bits_to_f32(w2[j])));
+            x1[j] = round_to_bf16(__fmul_rn(round_to_bf16(__fmul_rn(x1[j], inv)), bf16_bits_to_f32(pre.w1[j])));
+            x2[j] = round_to_bf16(__fmul_rn(round_to_bf16(__fmul_rn(x2[j], inv)), bf16_bits_to_f32(pre.w2[j])));
         }
     }
-    const float* cs = r.cos_sin + r.positions[t] * 128 + s8;
     u16x8 y1, y2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float c = cs[j], sn = cs[64 + j];
+        const float c = pre.c[j], sn = pre.sn[j];
         y1[j] = f32_to_bf16_bits(__builtin_fmaf(x1[j], c, -__fmul_rn(x2[j], sn)));
         y2[j] = f32_to_bf16_bits(__builtin_fmaf(x2[j], c, __fmul_rn(x1[j], sn)));
     }

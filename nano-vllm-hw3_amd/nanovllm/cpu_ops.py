@@ -20,7 +20,7 @@ def silu_mul(x):
 
 
 def _rope(x, positions, cos_sin):
-    cs = cos_sin[positions]                                   # [T, D] f32: cos | sin
+    cs = cos_sin[positions] if positions is not None else cos_sin      # [T, D] f32: cos | sin
     half = cs.shape[-1] // 2
     cos, sin = cs[:, None, :half], cs[:, None, half:]
     x1, x2 = x.float()[..., :half], x.float()[..., half:]

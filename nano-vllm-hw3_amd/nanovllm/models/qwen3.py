@@ -25,6 +25,9 @@ class AttnContext:
     block_tables: Optional[torch.Tensor] = None
     cu_seqlens_dev: Optional[torch.Tensor] = None   # cu_seqlens as int32 on the device (built on demand)
     max_seqlen: int = 0
+    # optional [T, head_dim] f32: the RoPE table rows of this step's tokens gathered by the caller (measured no
+    # faster than letting every layer's launch look its rows up, so the engine leaves it unset)
+    cos_sin_rows: Optional[torch.Tensor] = None
 
 
 _CTX = AttnContext()
@@ -128,7 +131,9 @@ class Qwen3Attention(nn.Module):
         if FUSE_QKV_ROPE and hasattr(self.qkv_proj, "qw") and self.head_dim == 128 and self.qkv_proj.qw.shape[1] % 32 == 0:
             # quantized qkv projection: q/k norm + RoPE + KV-cache store run in the GEMM's epilogue (one launch)
             from nanovllm.utils.quantization import qkv_rope_matmul
-            q, k, v = qkv_rope_matmul(self.qkv_proj, hidden_states, positions, self.cos_sin, qw, kw, self.eps,
+            rows = ctx.cos_sin_rows
+            q, k, v = qkv_rope_matmul(self.qkv_proj, hidden_states, positions if rows is None else None,
+                                      self.cos_sin if rows is None else rows, qw, kw, self.eps,
                                       self.num_heads, self.num_kv_heads, self.head_dim, self.k_cache, self.v_cache,
                                       ctx.slot_mapping, want_kv=ctx.is_prefill, quantized=quantized)
         else:

@@ -73,7 +73,7 @@ def qknorm_rope_store(qkv, positions, cos_sin, q_norm_w, k_norm_w, eps, num_head
     v = torch.empty((T, num_kv_heads, head_dim), dtype=BF16, device=qkv.device) if want_kv else None
     use_cache = slot_mapping is not None and k_cache is not None and k_cache.numel() > 0
     Q.check(Q.load().ql_qknorm_rope_store(
-        qkv.data_ptr(), positions.data_ptr(), cos_sin.data_ptr(),
+        qkv.data_ptr(), positions.data_ptr() if positions is not None else None, cos_sin.data_ptr(),
         q_norm_w.data_ptr() if q_norm_w is not None else None,
         k_norm_w.data_ptr() if k_norm_w is not None else None, eps, q.data_ptr(),
         k.data_ptr() if want_kv else None, v.data_ptr() if want_kv else None,

@@ -231,7 +231,8 @@ def qkv_rope_matmul(mod, x, positions, cos_sin, q_norm_w, k_norm_w, eps, num_hea
     """The qkv projection of a quantized module with q/k norm + RoPE + KV-cache store in the GEMM epilogue
     (qwen3.py:80-88 + attention.py:52-58 of the reference in one launch): returns (q [T,Hq,D], k, v) like
     ops.qknorm_rope_store and never materialises the [T, N] projection.  ``quantized`` = (qx, sx) for a W8A8
-    module whose input was quantized by the preceding norm."""
+    module whose input was quantized by the preceding norm.  ``positions=None``: ``cos_sin`` is [T, D], the table
+    rows of the tokens gathered once by the caller."""
     lib = Q.load()
     dtype = mod.dtype
     N, K = mod.qw.shape
@@ -253,7 +254,9 @@ def qkv_rope_matmul(mod, x, positions, cos_sin, q_norm_w, k_norm_w, eps, num_hea
     v = torch.empty((T, num_kv_heads, head_dim), dtype=torch.bfloat16, device=dev) if want_kv else None
     use_cache = slot_mapping is not None and k_cache is not None and k_cache.numel() > 0
     bias = mod._bias_for_rank()
-    tail = (positions.data_ptr(), cos_sin.data_ptr(), q_norm_w.data_ptr() if q_norm_w is not None else None,
+    if positions is None:
+        assert cos_sin.shape[0] == T, "without positions, cos_sin holds one gathered row per token"
+    tail = (positions.data_ptr() if positions is not None else None, cos_sin.data_ptr(), q_norm_w.data_ptr() if q_norm_w is not None else None,
             k_norm_w.data_ptr() if k_norm_w is not None else None, eps, q.data_ptr(),
             k.data_ptr() if want_kv else None, v.data_ptr() if want_kv else None,
             k_cache.data_ptr() if use_cache else None, v_cache.data_ptr() if use_cache else None,

@@ -386,7 +386,10 @@ def _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, want_kv, quanti
     return outs
 
 
-@pytest.mark.parametrize("tile", [t for t in TILES if t[1] in (4, 8)])
+ROPE_TILES = [(1, 4, 2, 16), (1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4), (4, 8, 1, 4)]    # QL_TILE_LIST_ROPE
+
+
+@pytest.mark.parametrize("tile", ROPE_TILES)
 @pytest.mark.parametrize("split", [1, 3])
 def test_qkv_rope_epilogue_bit_identical(NQ, tile, split):
     """qkv GEMM with the q/k norm + RoPE + KV-cache store in its epilogue == the plain GEMM (same tile, same split)
@@ -431,6 +434,15 @@ def test_qkv_rope_full_size_own_tiles(NQ, M):
     qx, sx = NQ.per_row_quant(x, torch.int8)
     a, b = _rope_both_ways(NQ, mod, None, qn, kn, cs, pos, slots, Hq, Hkv, False, quantized=(qx, sx))
     assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    # positions=None: the table rows of the tokens handed in already gathered (fused and stand-alone operator)
+    rows = cs.index_select(0, pos)
+    kc = torch.zeros(16, 256, Hkv, 128, device="cuda", dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    q2, _, _ = NQ.qkv_rope_matmul(mod, x, None, rows, qn, kn, 1e-6, Hq, Hkv, 128, kc, vc, slots, False)
+    assert torch.equal(q2, b[0]) and torch.equal(kc, b[3]) and torch.equal(vc, b[4])
+    kc.zero_(); vc.zero_()
+    q3, _, _ = ops.qknorm_rope_store(mod(x), None, rows, qn, kn, 1e-6, Hq, Hkv, 128, kc, vc, slots, False)
+    assert torch.equal(q3, b[0]) and torch.equal(kc, b[3])
     for mk in (lambda: NQ.QLinear(torch.int8, w, None, weight_only=True), lambda: NQ.QGroupLinear(torch.float8_e4m3fn, w, None, 128)):
         mod = mk().tile()
         a, b = _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, False)
