@@ -141,6 +141,23 @@ int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x_bf16, const vo
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
                       const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* Weight-only GEMM whose split-K reduction is left to the NEXT launch.  For the projections that feed a residual
+ * add + RMSNorm (o_proj, down_proj: Qwen3DecoderLayer.forward, nanovllm/models/qwen3.py:153-162) the K dimension is
+ * cut into ql_gemm_partial_slices(M, N, K, granularity) slices, slice s stores its UNSCALED f32 partial sums at
+ * partials[s][M][N], and ql_add_rmsnorm_partial adds the slices in slice order, applies the GEMM's own epilogue
+ * (x = bf16(sum * sw[n] + bias), formulas of ql_gemm_w8a16) and continues as ql_add_rmsnorm(x, residual, ...).
+ * The pair is bit-identical to ql_gemm_w8a16 (same tile, same slices) followed by ql_add_rmsnorm; it removes the
+ * ticket + second pass from the GEMM's tail, so K can be cut finely enough to occupy the chip at decode sizes.
+ * `slices` must be the value ql_gemm_partial_slices returns for the same arguments; no workspace.  sw / bias of
+ * ql_add_rmsnorm_partial are the GEMM's (sw ignored for QL_PER_GROUP: group scales are applied inside the GEMM);
+ * residual and residual_out are required. */
+int ql_gemm_partial_slices(int64_t M, int64_t N, int64_t K, int granularity);
+int ql_gemm_w8a16_partial(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw, int64_t M,
+                          int64_t N, int64_t K, int group, float* partials, int slices, void* stream);
+int ql_add_rmsnorm_partial(const float* partials, int slices, int granularity, const float* sw, const void* bias_bf16,
+                           const void* residual_bf16, const void* weight_bf16, float eps, void* out_bf16,
+                           void* residual_out_bf16, int64_t T, int64_t H, void* stream);
+
 /* The qkv projection with everything between it and attention fused into the GEMM epilogue
  * (Qwen3Attention.forward, nanovllm/models/qwen3.py:80-88: qkv_proj, split, q_norm / k_norm, rotary_emb, and the
  * store_kvcache of nanovllm/layers/attention.py:10-40, 52-58): the [M, N] projection is never written; every

@@ -113,6 +113,44 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     return pl;
 }
 
+// Plan of the deferred-reduction form (ql_gemm_w8a16_partial): K is cut into as many slices as it takes to give the
+// chip about one workgroup per CU; nothing is combined in the kernel, so slices cost no tail.
+static Plan make_plan_partial(int64_t M, int64_t N, int64_t K, bool group) {
+    Plan pl;
+    // Measured on the Qwen3-0.6B o_proj / down_proj shapes (tools/bench_partial.py): one 1024-k chunk per
+    // workgroup wherever possible.  The 32 x 32 tile (eight waves over the chunk, two workgroups per CU) is best
+    // up to one workgroup per CU and again when there are too many tiles for anything else; in between, the
+    // 32 x 64 tile (one workgroup per CU) halves the activation re-reads.
+    const int64_t mb = (M + 31) / 32, kc = (K + 1023) / 1024;
+    const int64_t base32 = mb * ((N + 31) / 32), base64 = mb * ((N + 63) / 64);
+    int mt = 1, wn = 1, wk = 8, cp = 4;
+    int64_t cap = 512;
+    if (base32 * kc > 256 && base64 * kc <= 256) { wn = 2; wk = 4; cp = 8; cap = 256; }
+    if (M > 256) { mt = 2; wn = 2; wk = 4; cp = 8; cap = 256; }          // 64 x 64
+    if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group)) {
+        mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
+    }
+    pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
+    const int kb = 32 * cp * wk;
+    const int64_t mblocks = (M + 32 * mt - 1) / (32 * mt), nblocks = (N + 32 * wn - 1) / (32 * wn);
+    const int64_t kchunks = (K + kb - 1) / kb, base = mblocks * nblocks;
+    int64_t split = kchunks;                                 // one chunk per slice ...
+    while (split > 1 && base * split > cap) --split;         // ... unless that is more than one round of workgroups
+    // two slices of a grid that already has a workgroup per CU gain less than the consumer's extra reads cost
+    // (measured): report one slice, and the caller keeps the self-contained GEMM
+    if (split == 2 && base32 * kc > 256) split = 1;
+    if (f_split > 0) split = f_split;
+    if (split > kchunks) split = kchunks;
+    if (split > 16) split = 16;
+    if (split < 1) split = 1;
+    const int64_t cps = (kchunks + split - 1) / split;
+    split = (kchunks + cps - 1) / cps;
+    pl.split = (int)split;
+    pl.k_per_split = (int)(cps * kb);
+    pl.grid = dim3((unsigned)nblocks, (unsigned)mblocks, (unsigned)split);
+    return pl;
+}
+
 static size_t plan_workspace(const Plan& pl) {
     if (pl.split <= 1) return 0;
     const size_t tiles = (size_t)pl.grid.x * pl.grid.y;
@@ -308,6 +346,51 @@ int ql_gemm_w8a16(int wdtype, int granularity, const void* x, const void* qw, co
                   void* stream) {
     return gemm_w8a16("ql_gemm_w8a16", false, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, workspace,
                       workspace_bytes, stream);
+}
+
+int ql_gemm_partial_slices(int64_t M, int64_t N, int64_t K, int granularity) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
+    return make_plan_partial(M, N, K, granularity == QL_PER_GROUP).split;
+}
+
+int ql_gemm_w8a16_partial(int wdtype, int granularity, const void* x, const void* qw, const float* sw, int64_t M, int64_t N,
+                          int64_t K, int group, float* partials, int slices, void* stream) {
+    const char* fn = "ql_gemm_w8a16_partial";
+    const bool tiled = (wdtype & QL_TILED) != 0;
+    wdtype &= ~QL_TILED;
+    if ((wdtype != QL_INT8 && wdtype != QL_FP8) || granularity < QL_PER_ROW || granularity > QL_PER_GROUP ||
+        (M > 0 && (!x || !partials)) || !qw || !sw) {
+        set_error("%s: bad argument (wdtype=%d granularity=%d)", fn, wdtype, granularity);
+        return QL_EINVAL;
+    }
+    int rc = check_common(fn, M, N, K);
+    if (rc) return rc;
+    const bool grp = granularity == QL_PER_GROUP;
+    if (grp && !(group >= 32 && group % 32 == 0 && K % group == 0)) {
+        set_error("%s: group=%d unsupported for K=%lld", fn, group, (long long)K);
+        return QL_ESHAPE;
+    }
+    if (M == 0) return QL_OK;
+    const Plan pl = make_plan_partial(M, N, K, grp);
+    if (slices != pl.split) {
+        set_error("%s: slices=%d, but the plan for M=%lld N=%lld K=%lld has %d (ql_gemm_partial_slices)", fn, slices,
+                  (long long)M, (long long)N, (long long)K, pl.split);
+        return QL_EINVAL;
+    }
+    GemmParams p{};
+    p.x = (const unsigned char*)x; p.w = (const unsigned char*)qw; p.sw = sw;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = grp ? group : 0;
+    p.sw_stride = granularity == QL_PER_ROW ? 1 : 0;
+    p.wtiled = tiled ? 1 : 0;
+    p.partial_rm = partials;
+    p.k_per_split = pl.k_per_split;
+    kern_t k;
+    if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp);
+    else k = grp ? pick_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp) : pick_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp);
+    if (!k) { set_error("%s: tile (%d,%d,%d,%d) not built", fn, pl.mt, pl.wn, pl.wk, pl.cp); return QL_EINVAL; }
+    hipLaunchKernelGGL(k, pl.grid, dim3(64 * pl.wn * pl.wk), 0, as_stream(stream), p);
+    QL_CHECK_LAUNCH(fn);
+    return QL_OK;
 }
 
 int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,

@@ -19,6 +19,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // activation quantization of the W8A8 linears, the reference's per_row_quant on x): q = cast(y * Q / max|y|),
 // scale = max|y| / Q with y the bf16 values the plain kernel would have stored, so (q, scale) are bit-identical
 // to ql_add_rmsnorm followed by ql_quant_per_row, without the launch and the bf16 round trip in between.
+// Where x comes from when the producing GEMM left its split-K reduction to this launch (ql_gemm_w8a16_partial):
+// x[t, n] = bf16( (sum over slices, in slice order, of part[s][t][n]) * sw[n] (+ bias[n]) ), the GEMM's own epilogue.
+struct PartialSrc {
+    const float* part;            // [S][T][H] f32, or null: x is read as bf16
+    const float* sw;              // per-row [H] (stride 1), per-tensor [1] (stride 0), or null = 1 (per-group: already scaled)
+    const unsigned short* bias;   // [H] bf16 or null
+    int64_t slab;                 // T * H
+    int S, sw_stride, bias_after_round;
+};
+
 template <int NV, int QDT>   // 16-byte vectors per thread
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* __restrict__ x,
                                                           const unsigned short* __restrict__ res,
@@ -26,7 +36,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
                                                           unsigned short* __restrict__ out,
                                                           unsigned short* __restrict__ res_out, int H, float eps,
                                                           unsigned char* __restrict__ q_out,
-                                                          float* __restrict__ scale_out) {
+                                                          float* __restrict__ scale_out, const PartialSrc ps) {
     __shared__ float sh[8];
     const size_t row = blockIdx.x;
     const int nvec = H >> 3;
@@ -37,10 +47,55 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
     for (int j = 0; j < NV; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < nvec) {
-            const u16x8 a = *(const u16x8*)(x + row * H + c * 8);
+            u16x8 a, b = {0, 0, 0, 0, 0, 0, 0, 0};
             ww[j] = *(const u16x8*)(w + c * 8);
+            if (res) b = *(const u16x8*)(res + row * H + c * 8);
+            if (ps.part) {
+                // everything this piece needs is requested before the first wait: residual (above), scales, bias
+                // and the slices' partial sums (four slices in flight at a time; the additions stay in slice order)
+                float sc[8];
+                u16x8 bb = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ps.sw && ps.sw_stride) {
+                    const float4 s0 = *(const float4*)(ps.sw + c * 8), s1 = *(const float4*)(ps.sw + c * 8 + 4);
+                    sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+                } else {
+                    const float s0 = ps.sw ? ps.sw[0] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sc[k] = s0;
+                }
+                if (ps.bias) bb = *(const u16x8*)(ps.bias + c * 8);
+                float acc[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+                const float* src = ps.part + row * H + c * 8;
+                for (int s0 = 0; s0 < ps.S; s0 += 4) {
+                    float4 p0[4], p1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* q = src + (size_t)min(s0 + u, ps.S - 1) * ps.slab;
+                        p0[u] = *(const float4*)q;
+                        p1[u] = *(const float4*)(q + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s0 + u < ps.S) {
+                            acc[0] += p0[u].x; acc[1] += p0[u].y; acc[2] += p0[u].z; acc[3] += p0[u].w;
+                            acc[4] += p1[u].x; acc[5] += p1[u].y; acc[6] += p1[u].z; acc[7] += p1[u].w;
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v = __fmul_rn(acc[k], sc[k]);
+                    if (ps.bias) {
+                        const float bv = bf16_bits_to_f32(bb[k]);
+                        v = ps.bias_after_round ? __fadd_rn((float)(bf16_t)v, bv) : __fadd_rn(v, bv);
+                    }
+                    a[k] = __builtin_bit_cast(unsigned short, (bf16_t)v);
+                }
+            } else {
+                a = *(const u16x8*)(x + row * H + c * 8);
+            }
             if (res) {
-                const u16x8 b = *(const u16x8*)(res + row * H + c * 8);
                 u16x8 r;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -334,8 +389,8 @@ extern "C" {
 
 static int add_rmsnorm_launch(const char* fn, int qdt, const void* x, const void* residual, const void* weight, float eps,
                               void* out, void* residual_out, void* q_out, float* scale_out, int64_t T, int64_t H,
-                              void* stream) {
-    if (!weight || T < 0 || H <= 0 || (T > 0 && !x) || (residual && !residual_out) ||
+                              void* stream, PartialSrc ps = PartialSrc{}) {
+    if (!weight || T < 0 || H <= 0 || (T > 0 && !x && !ps.part) || (residual && !residual_out) ||
         (T > 0 && (qdt < 0 ? !out : (!q_out || !scale_out)))) {
         set_error("%s: bad argument", fn);
         return QL_EINVAL;
@@ -349,7 +404,7 @@ static int add_rmsnorm_launch(const char* fn, int qdt, const void* x, const void
     hipStream_t s = as_stream(stream);
 #define QL_RMS(NV, QDT) hipLaunchKernelGGL((add_rmsnorm_kernel<NV, QDT>), grid, block, 0, s, (const unsigned short*)x, \
         (const unsigned short*)residual, (const unsigned short*)weight, (unsigned short*)out, (unsigned short*)residual_out, \
-        (int)H, eps, (unsigned char*)q_out, scale_out)
+        (int)H, eps, (unsigned char*)q_out, scale_out, ps)
 #define QL_RMS_NV(QDT) do { if (nv == 1) QL_RMS(1, QDT); else if (nv == 2) QL_RMS(2, QDT); else QL_RMS(4, QDT); } while (0)
     if (qdt < 0) QL_RMS_NV(-1); else if (qdt == QL_INT8) QL_RMS_NV(QL_INT8); else QL_RMS_NV(QL_FP8);
 #undef QL_RMS_NV
@@ -368,6 +423,24 @@ int ql_add_rmsnorm_quant(int dtype, const void* x, const void* residual, const v
                          float* scale_out, void* residual_out, int64_t T, int64_t H, void* stream) {
     return add_rmsnorm_launch("ql_add_rmsnorm_quant", dtype, x, residual, weight, eps, nullptr, residual_out, q_out,
                               scale_out, T, H, stream);
+}
+
+int ql_add_rmsnorm_partial(const float* partials, int slices, int granularity, const float* sw, const void* bias,
+                           const void* residual, const void* weight, float eps, void* out, void* residual_out, int64_t T,
+                           int64_t H, void* stream) {
+    const char* fn = "ql_add_rmsnorm_partial";
+    if (!partials || slices < 1 || granularity < QL_PER_ROW || granularity > QL_PER_GROUP ||
+        (granularity != QL_PER_GROUP && !sw) || !residual || !residual_out) {
+        set_error("%s: bad argument (a deferred GEMM output always joins a residual)", fn);
+        return QL_EINVAL;
+    }
+    PartialSrc ps{};
+    ps.part = partials; ps.S = slices; ps.slab = T * H;
+    ps.sw = granularity == QL_PER_GROUP ? nullptr : sw;
+    ps.sw_stride = granularity == QL_PER_ROW ? 1 : 0;
+    ps.bias = (const unsigned short*)bias;
+    ps.bias_after_round = granularity == QL_PER_ROW ? 0 : 1;
+    return add_rmsnorm_launch(fn, -1, nullptr, residual, weight, eps, out, residual_out, nullptr, nullptr, T, H, stream, ps);
 }
 
 int ql_silu_mul(const void* x, void* out, int64_t T, int64_t I, void* stream) {

@@ -37,6 +37,10 @@ SIGNATURES = {
     "ql_gemm_w8a16_silu": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                     _c_int, _c_vp]),
     "ql_gemm_w8a8_silu": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ql_gemm_partial_slices": (_c_int, [_c_i64, _c_i64, _c_i64, _c_int]),
+    "ql_gemm_w8a16_partial": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_int, _c_vp]),
+    "ql_add_rmsnorm_partial": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp,
+                                        _c_i64, _c_i64, _c_vp]),
     "ql_gemm_w8a16_rope": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_vp,
                                     _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int,
                                     _c_int, _c_vp, _c_sz, _c_vp]),

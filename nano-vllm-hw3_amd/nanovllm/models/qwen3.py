@@ -149,7 +149,9 @@ class Qwen3Attention(nn.Module):
             o = ops.attn_prefill(q, k, v, cu_dev, max_len, self.scaling)
         else:
             o = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scaling)
-        return self.o_proj(o.view(o.shape[0], -1))
+        o = o.view(o.shape[0], -1)
+        # (a quantized o_proj may leave its split-K reduction to the residual add + RMSNorm launch behind it)
+        return self.o_proj.forward_partial(o) if hasattr(self.o_proj, "forward_partial") else self.o_proj(o)
 
 
 class Qwen3MLP(nn.Module):
@@ -163,7 +165,7 @@ class Qwen3MLP(nn.Module):
         h = self.gate_up_proj(x) if quantized is None else self.gate_up_proj.forward_quantized(*quantized)
         if not getattr(self.gate_up_proj, "silu_fused", False):   # else the GEMM epilogue already applied SiLU * mul
             h = ops.silu_mul(h)
-        return self.down_proj(h)
+        return self.down_proj.forward_partial(h) if hasattr(self.down_proj, "forward_partial") else self.down_proj(h)
 
 
 class Qwen3DecoderLayer(nn.Module):

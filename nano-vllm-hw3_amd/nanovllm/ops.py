@@ -11,7 +11,10 @@ BF16 = torch.bfloat16
 
 
 def add_rmsnorm(x, residual, weight, eps):
-    """Returns (normed, new_residual); new_residual is x when residual is None."""
+    """Returns (normed, new_residual); new_residual is x when residual is None.  x may be a PartialSum (a GEMM
+    output whose split-K reduction and epilogue this launch performs)."""
+    if hasattr(x, "parts"):
+        return _add_rmsnorm_partial(x, residual, weight, eps)
     if not x.is_cuda:
         return cpu_ops.add_rmsnorm(x, residual, weight, eps)
     Q.require_cuda(x, BF16, "x")
@@ -26,6 +29,19 @@ def add_rmsnorm(x, residual, weight, eps):
     res_out = torch.empty_like(x)
     Q.check(Q.load().ql_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), eps, out.data_ptr(),
                                     res_out.data_ptr(), T, H, Q.stream_ptr(x.device)))
+    return out, res_out
+
+
+def _add_rmsnorm_partial(ps, residual, weight, eps):
+    assert residual is not None, "a deferred GEMM output always joins a residual"
+    Q.require_cuda(residual, BF16, "residual")
+    S, T, H = ps.parts.shape
+    out = torch.empty(ps.shape, dtype=BF16, device=residual.device)
+    res_out = torch.empty_like(out)
+    Q.check(Q.load().ql_add_rmsnorm_partial(ps.parts.data_ptr(), S, ps.granularity, ps.sw.data_ptr(),
+                                            ps.bias.data_ptr() if ps.bias is not None else None, residual.data_ptr(),
+                                            weight.data_ptr(), eps, out.data_ptr(), res_out.data_ptr(), T, H,
+                                            Q.stream_ptr(residual.device)))
     return out, res_out
 
 

@@ -20,6 +20,10 @@ import torch.distributed as dist
 from nanovllm import _qlinear as Q
 
 _DTYPES = [torch.float8_e4m3fn, torch.int8]
+# o_proj / down_proj of a weight-only quantized model hand their split-K reduction to the norm launch behind them
+# (NANOVLLM_NO_DEFER_SPLITK=1 keeps the self-contained GEMM, for A/B measurements)
+import os as _os
+DEFER_SPLITK = _os.environ.get("NANOVLLM_NO_DEFER_SPLITK", "") == ""
 
 
 _scratch16 = {}
@@ -225,6 +229,39 @@ def per_row_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
     return w8a8_matmul(qx, sx, qw, sw, bias, dtype, None if out is not None else y_shape, silu, out)
 
 
+class PartialSum:
+    """Output of a weight-only GEMM whose split-K reduction and epilogue are left to the residual add + RMSNorm
+    launch that consumes it (ops.add_rmsnorm accepts it in place of x): ``parts`` [S, M, N] f32 unscaled partial
+    sums, plus the scale / bias the epilogue applies."""
+
+    def __init__(self, parts, granularity, sw, bias, shape):
+        self.parts, self.granularity, self.sw, self.bias, self.shape = parts, granularity, sw, bias, shape
+
+    def dim(self):
+        return len(self.shape)
+
+
+@torch.no_grad()
+def w8a16_partial_matmul(mod, x):
+    """``mod`` (a weight-only quantized module) applied to x with the split-K reduction deferred: a PartialSum."""
+    lib = Q.load()
+    dtype = mod.dtype
+    N, K = mod.qw.shape
+    x2 = Q.require_cuda(x.reshape(-1, x.shape[-1]), torch.bfloat16, "x")
+    M = x2.shape[0]
+    if isinstance(mod, QGroupLinear):
+        gran, group, sw = Q.QL_PER_GROUP, mod.group_size, mod.sw
+    elif isinstance(mod, QTensorLinear):
+        gran, group, sw = Q.QL_PER_TENSOR, 0, mod._sw32
+    else:
+        gran, group, sw = Q.QL_PER_ROW, 0, mod.sw
+    S = lib.ql_gemm_partial_slices(M, N, K, gran)
+    parts = torch.empty((max(S, 1), M, N), dtype=torch.float32, device=x.device)
+    Q.check(lib.ql_gemm_w8a16_partial(_wcode(mod.qw, dtype), gran, x2.data_ptr(), mod.qw.data_ptr(), sw.data_ptr(), M, N, K,
+                                      group, parts.data_ptr(), S, Q.stream_ptr(x.device)))
+    return PartialSum(parts, gran, sw, mod._bias_for_rank(), tuple(x.shape[:-1]) + (N,))
+
+
 @torch.no_grad()
 def qkv_rope_matmul(mod, x, positions, cos_sin, q_norm_w, k_norm_w, eps, num_heads, num_kv_heads, head_dim,
                     k_cache=None, v_cache=None, slot_mapping=None, want_kv=True, quantized=None):
@@ -348,6 +385,23 @@ class _QBase(torch.nn.Module):
 
     def rowmajor_qw(self):
         return self.qw.to_rowmajor() if isinstance(self.qw, TiledWeight) else self.qw
+
+    # largest row count for which a projection that feeds a residual add + RMSNorm leaves its split-K reduction to
+    # that launch (decode sizes; a prefill-sized f32 partial would double the bytes of the output)
+    PARTIAL_MAX_ROWS = 512
+
+    def forward_partial(self, x):
+        """forward() for a projection whose output goes straight into ops.add_rmsnorm: where it pays (weight-only
+        arithmetic, decode-sized input, no tensor-parallel all-reduce in between) the result is a PartialSum that
+        the norm launch finishes; otherwise the plain output."""
+        weight_only = not isinstance(self, QLinear) or self.weight_only
+        m = x.numel() // x.shape[-1]
+        if (DEFER_SPLITK and weight_only and not self.silu_fused and not (self.tp_dim == 1 and self.tp_size > 1)
+                and 0 < m <= self.PARTIAL_MAX_ROWS and x.dim() == 2):
+            gran = Q.QL_PER_GROUP if isinstance(self, QGroupLinear) else Q.QL_PER_TENSOR if isinstance(self, QTensorLinear) else Q.QL_PER_ROW
+            if Q.load().ql_gemm_partial_slices(m, self.qw.shape[0], self.qw.shape[1], gran) > 1:   # else: nothing to defer
+                return w8a16_partial_matmul(self, x)
+        return self(x)
 
     def _finish(self, y):
         if self.tp_dim == 1 and self.tp_size > 1:

@@ -452,6 +452,68 @@ def test_qkv_rope_full_size_own_tiles(NQ, M):
             assert (ta == tb).float().mean() > 0.9
 
 
+@pytest.mark.parametrize("tile", [(1, 1, 8, 4), (1, 1, 4, 4), (1, 1, 4, 2), (1, 2, 4, 8), (2, 2, 4, 8), (2, 4, 2, 4)])
+@pytest.mark.parametrize("split", [1, 2, 5])
+def test_deferred_splitk_norm_bit_identical(NQ, tile, split):
+    """GEMM with the split-K reduction left to the residual add + RMSNorm launch == the self-contained GEMM (same
+    tile, same slices) followed by ql_add_rmsnorm, bit for bit (normed output and new residual): per-row int8 / fp8,
+    per-tensor, per-group, with and without a bias, M and N tails, a ragged last slice."""
+    from nanovllm import _qlinear as Q, ops
+    lib = Q.load()
+    M, N, K = 70, 200, 1184
+    rng = np.random.default_rng(21)
+    x = bf16_t(rand_bf16(rng, (M, K)))
+    w = bf16_t(rand_bf16(rng, (N, K), 0.05))
+    bias = torch.nn.Parameter(bf16_t(rand_bf16(rng, (N,), 0.5)), requires_grad=False)
+    res = bf16_t(rand_bf16(rng, (M, N)))
+    nw = bf16_t(O.f32_to_bf16((1 + 0.1 * rng.standard_normal(N)).astype(np.float32)))
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], split) == 0
+        mods = [NQ.QLinear(torch.int8, w, None, weight_only=True), NQ.QLinear(torch.float8_e4m3fn, w, bias, weight_only=True),
+                NQ.QTensorLinear(torch.int8, w, bias), NQ.QGroupLinear(torch.float8_e4m3fn, w[:, :1152].contiguous(), None, 128),
+                NQ.QGroupLinear(torch.int8, w[:, :1152].contiguous(), bias, 384)]
+        for mi, mod in enumerate(mods):
+            mod.tile()
+            xx = x if mod.qw.shape[1] == K else x[:, :1152].contiguous()
+            ps = NQ.w8a16_partial_matmul(mod, xx)
+            assert ps.parts.shape[1:] == (M, N) and ps.parts.shape[0] == lib.ql_gemm_partial_slices(M, N, xx.shape[1], ps.granularity)
+            out, new_res = ops.add_rmsnorm(ps, res, nw, 1e-6)
+            ref_out, ref_res = ops.add_rmsnorm(mod(xx), res, nw, 1e-6)
+            assert torch.equal(new_res, ref_res) and torch.equal(out, ref_out), (mi, tile, split)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("nk", [(1024, 2048), (1024, 3072), (2560, 9728), (4096, 1536)])
+@pytest.mark.parametrize("M", [1, 16, 130, 256, 512])
+def test_deferred_splitk_full_size_own_plan(NQ, nk, M):
+    """o_proj / down_proj shapes with the library's own plans on both routes (they slice K differently, so the f32
+    sums differ in order): the normed output of the deferred route must agree with the self-contained route to the
+    GEMM's rounding level, and the module-level switch must route decode sizes through it."""
+    from nanovllm import ops
+    N, K = nk
+    g = torch.Generator(device="cuda").manual_seed(N + K + M)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda", dtype=torch.bfloat16, generator=g)
+    nw = torch.ones(N, device="cuda", dtype=torch.bfloat16)
+    mod = NQ.QLinear(torch.int8, w, None, weight_only=True).tile()
+    ps = mod.forward_partial(x)
+    if K >= 3072 and M <= 128:
+        assert isinstance(ps, NQ.PartialSum) and ps.parts.shape[0] >= 2
+    if torch.is_tensor(ps):                          # the plan has a single slice: nothing was deferred
+        ps = NQ.w8a16_partial_matmul(mod, x)
+    out, new_res = ops.add_rmsnorm(ps, res, nw, 1e-6)
+    ref_out, ref_res = ops.add_rmsnorm(mod(x), res, nw, 1e-6)
+    for a, b in ((new_res, ref_res), (out, ref_out)):
+        d = (a.float() - b.float()).abs()
+        assert (d <= 2.0 ** -6 * b.float().abs() + 2e-2).all()
+        assert (a == b).float().mean() > 0.9
+    assert torch.is_tensor(NQ.QLinear(torch.int8, w, None).tile().forward_partial(x))          # W8A8: self-contained
+    big = torch.randn(mod.PARTIAL_MAX_ROWS + 1, K, device="cuda", dtype=torch.bfloat16)
+    assert torch.is_tensor(mod.forward_partial(big))
+
+
 @pytest.mark.parametrize("M", [1, 16, 33, 130, 256, 2048])
 def test_fused_silu_full_size_and_module(NQ, M):
     """Qwen3-0.6B gate/up shape through the module API with the library's own tile choice: int8 W8A8 is
