@@ -128,7 +128,7 @@ def measure_decode_gemm(llm, step_batches):
     attn0 = layers[0].self_attn
     hidden = mods[0][1].qw.shape[0]
     nw = torch.ones(hidden, device="cuda", dtype=torch.bfloat16)
-    tot_t = tot_b = tot_n = tot_plain = 0.0
+    tot_t = tot_b = tot_n = tot_plain = tot_raw = tot_rope = 0.0
     side = torch.cuda.Stream()
     with torch.inference_mode():
         for M, cnt in sorted(buckets.items()):
@@ -138,14 +138,14 @@ def measure_decode_gemm(llm, step_batches):
             slots = torch.arange(M, device="cuda", dtype=torch.int32)
             deferred = [0]
 
-            def gemms(count_only=False):
+            def gemms(with_norms=True):
                 for li, m4 in enumerate(mods):
                     at = layers[li].self_attn
                     qkv_rope_matmul(m4[0], xs[0], pos, at.cos_sin, at.q_norm.weight, at.k_norm.weight, at.eps, at.num_heads,
                                     at.num_kv_heads, at.head_dim, at.k_cache, at.v_cache, slots, want_kv=False)
                     for k in (1, 3):
                         y = m4[k].forward_partial(xs[k])
-                        if isinstance(y, PartialSum):
+                        if isinstance(y, PartialSum) and with_norms:
                             ops.add_rmsnorm(y, res, nw, 1e-6)
                             deferred[0] += 1
                     m4[2](xs[2])
@@ -153,6 +153,14 @@ def measure_decode_gemm(llm, step_batches):
             def norms():
                 for _ in range(deferred[0]):
                     ops.add_rmsnorm(res, res, nw, 1e-6)
+
+            qkv_out = torch.randn(M, mods[0][0].qw.shape[0], device="cuda", dtype=torch.bfloat16)
+
+            def ropes():                # the stand-alone operator the qkv epilogue replaces, once per layer
+                for li in range(len(mods)):
+                    at = layers[li].self_attn
+                    ops.qknorm_rope_store(qkv_out, pos, at.cos_sin, at.q_norm.weight, at.k_norm.weight, at.eps, at.num_heads,
+                                          at.num_kv_heads, at.head_dim, at.k_cache, at.v_cache, slots, want_kv=False)
             def plain():                # the self-contained form of every launch (last round's methodology)
                 for m4 in mods:
                     for x, m in zip(xs, m4):
@@ -164,6 +172,8 @@ def measure_decode_gemm(llm, step_batches):
             t1 = _graph_time(gemms, side)
             t0 = _graph_time(norms, side) if deferred[0] else 0.0
             tot_plain += _graph_time(plain, side) * cnt
+            tot_raw += _graph_time(lambda: gemms(False), side) * cnt
+            tot_rope += _graph_time(ropes, side) * cnt
             nbytes = sum(gemm_bytes(M, m.qw.shape[0], m.qw.shape[1],
                                     m.qw.shape[0] // 2 if getattr(m, "silu_fused", False) else None)
                          for m4 in mods for m in m4)
@@ -179,7 +189,13 @@ def measure_decode_gemm(llm, step_batches):
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(mods[0], buckets),
             "kernel": "ql::qgemm_kernel (decode W8A16 GEMM, all four layer shapes as the decode graph launches them, "
                       "M = graph bucket)",
-            "avg_launch_us": round(avg_us, 2), "avg_launch_us_self_contained_form": round(tot_plain / tot_n * 1e6, 2),
+            "avg_launch_us": round(avg_us, 2),
+            # the same launches without the norms that finish the deferred reductions (what a kernel trace shows
+            # for these kernels, plus the launch gap), their self-contained form (last round's methodology), and
+            # the launches' cost net of the stand-alone RoPE operator their epilogue replaced
+            "avg_launch_us_gemm_launches_only": round(tot_raw / tot_n * 1e6, 2),
+            "avg_launch_us_self_contained_form": round(tot_plain / tot_n * 1e6, 2),
+            "avg_launch_us_net_of_replaced_rope_launch": round((tot_t - tot_rope) / tot_n * 1e6, 2),
             "avg_algorithmic_bytes": int(tot_b / tot_n),
             "launches_weighted": int(tot_n)}
 
