@@ -237,7 +237,13 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     }
 
     constexpr int D = DB ? CP : (CP < 8 ? CP : 8);               // weight loads in flight per lane
+    // DEEP (the 8-strip prefill tiles on 16-bit activations): activations and weights are requested TWO chunks
+    // ahead.  Every chunk ends on a workgroup barrier behind the slowest of its 4096 16-byte requests, and with long
+    // K slices one chunk of lead does not cover that tail; a second register set per operand buys a second chunk of
+    // lead, while two LDS buffers still suffice.
+    constexpr bool DEEP = DB && WN == 8 && ACT == ACT_BF16;
     i32x4 wcur[D], wnext[(DB && WN != 8) ? CP : 1], sreg[C::NP];
+    i32x4 wcur2[DEEP ? CP : 1], sreg2[DEEP ? C::NP : 1];
 
     // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
     auto load_w1 = [&](auto chk, int kc, int c) -> i32x4 {
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         if (!decltype(chk)::value || kb < kend) return gload16(p.w + kb * kmul + woff);
         return i32x4{0, 0, 0, 0};
     };
-    auto load_x = [&](auto chk, int kc) {
+    auto load_x_to = [&](auto chk, int kc, i32x4* sreg) {
         if (fullM) {
             const bool ok = !decltype(chk)::value || (kc + st_k < kend);
             const unsigned off = ok ? xoff0 : (unsigned)(m0 * p.K) * C::AB;      // any valid address when past the slice
@@ -265,11 +271,13 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             }
         }
     };
-    auto store_x = [&](int buf) {
+    auto store_x_from = [&](int buf, const i32x4* sreg) {
 #pragma unroll
         for (int j = 0; j < C::NP; ++j)
             *(i32x4*)(smem + buf * C::XBYTES + lds_off<RB>(st_row0 + j * RS, st_ci)) = sreg[j];
     };
+    auto load_x = [&](auto chk, int kc) { load_x_to(chk, kc, sreg); };
+    auto store_x = [&](int buf) { store_x_from(buf, sreg); };
     auto flush_group = [&](int kb) {
         // fold the finished group's partial sums into the running sum with the group's f32 scale
         const float s = p.sw[(size_t)nrow * (p.K / p.group) + kb / p.group];
@@ -370,6 +378,22 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         }
         __syncthreads();
     };
+    // DEEP: chunk `it` (parity PAR) computes from LDS buffer PAR and weight set PAR, requests chunk it + 2 into the
+    // registers it frees, and ends by writing chunk it + 1 (requested during chunk it - 1) to the other LDS buffer
+    auto chunk_deep = [&](auto chk, auto par, int it) {
+        constexpr int PAR = decltype(par)::value;
+        const int kc = k0 + it * C::KB;
+        i32x4* wset = PAR ? wcur2 : wcur;
+        if (it + 2 < nchunks) load_x_to(TrueT{}, kc + 2 * C::KB, PAR ? sreg2 : sreg);
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            const i32x4 w = wset[c];
+            wset[c] = load_w_ring(kc + 2 * C::KB, c);
+            step(chk, PAR, kc, c, w);
+        }
+        if (it + 1 < nchunks) store_x_from(PAR ^ 1, PAR ? sreg : sreg2);
+        __syncthreads();
+    };
     auto chunk_sb = [&](auto chk, int it) {
         const int kc = k0 + it * C::KB;
         // activations first: the wait counter is positional, so staging them must not wait for the (slower,
@@ -390,7 +414,34 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         __syncthreads();
     };
 
-    if constexpr (DB) {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if constexpr (DEEP) {
+        if (nchunks > 0) {
+            load_x_to(TrueT{}, k0, sreg);                         // (before the weights: positional wait counter)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) wcur[c] = load_w1(TrueT{}, k0, c);
+            if (nchunks > 1) load_x_to(TrueT{}, k0 + C::KB, sreg2);
+#pragma unroll
+            for (int c = 0; c < CP; ++c) wcur2[c] = load_w_ring(k0 + C::KB, c);
+            store_x_from(0, sreg);
+        }
+        __syncthreads();
+        // whole chunks in pairs (the register sets alternate with the chunk's parity), then what is left: at most
+        // one whole chunk and at most one ragged one
+        const int nfull = (kend - k0) / C::KB;
+        int it = 0;
+        for (; it + 1 < nfull; it += 2) {
+            chunk_deep(FalseT{}, I0{}, it);
+            chunk_deep(FalseT{}, I1{}, it + 1);
+        }
+        if (it < nfull) {
+            chunk_deep(FalseT{}, I0{}, it);
+            if (it + 1 < nchunks) chunk_deep(TrueT{}, I1{}, it + 1);
+        } else if (it < nchunks) {
+            chunk_deep(TrueT{}, I0{}, it);
+        }
+    } else if constexpr (DB) {
         // LDS double buffer for x, register double buffer for the weights
         if (nchunks > 0) {
             load_x(TrueT{}, k0);                                  // (before the weights: positional wait counter)
@@ -399,10 +450,12 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             store_x(0);
         }
         __syncthreads();
-        for (int it = 0; it < nchunks; ++it) {
-            if (k0 + (it + 1) * C::KB <= kend) chunk_db(FalseT{}, it);
-            else chunk_db(TrueT{}, it);
-        }
+        // (whole chunks in a loop of ONE body, the ragged last chunk after it: with both variants inside the loop
+        // the accumulators get a second home, which costs the large tiles 60-150 registers or spills)
+        const int nfull = (kend - k0) / C::KB;
+        int it = 0;
+        for (; it < nfull; ++it) chunk_db(FalseT{}, it);
+        if (it < nchunks) chunk_db(TrueT{}, it);
     } else {
         // single buffer: the activation tile of the whole K slice (normally ONE chunk) is resident in
         // LDS; after the one staging barrier every wave streams its weights through a register ring

@@ -1,5 +1,7 @@
+# usage: tools/pmc_prefill_run.sh <tag> <counter> [<counter> ...]   (one --pmc pass over tools/pmc_prefill.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/pmc_pf
-timeout -s KILL 90 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_pf -- python3 -u $R/tools/pmc_prefill.py > $R/gpurun_out/pmc_pf/run.log 2>&1
+TAG=$1; shift
+mkdir -p $R/gpurun_out/pmc_pf_$TAG
+timeout -s KILL 90 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_pf_$TAG -- python3 -u $R/tools/pmc_prefill.py > $R/gpurun_out/pmc_pf_$TAG/run.log 2>&1
 echo rc=$?
