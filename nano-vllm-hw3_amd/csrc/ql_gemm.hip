@@ -67,8 +67,10 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     if (M > 1024) {
         mt = 2; wn = 4; wk = 1; cp = 4;
         // with enough 128 x 256 tiles to fill the chip, the wide 8-wave tile halves the L2->LDS bytes
-        // per MFMA (measured +25 % at M = 16384); 128-k chunks give its loads a whole chunk of MFMAs to land
-        if (!group && ((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = 4; }
+        // per MFMA (measured +25 % at M = 16384); 128-k chunks give its loads a whole chunk of MFMAs to land.
+        // Per-group scales keep a second accumulator set, which fits beside 64-k chunks only (measured -24 % at
+        // M = 16384 against the 64 x 128 tile, and ahead of the 128-k form on every shape).
+        if (((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = group ? 2 : 4; }
     }
     if (rope) {
         // the q/k norm + RoPE epilogue needs whole 128-column heads in one workgroup (4 or 8 column strips).

@@ -693,7 +693,7 @@ struct TileCfg { int mt, wn, wk, cp, db; };
     X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)
 #define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
 // tiles also built with the qkv (q/k norm + RoPE + KV store) epilogue: 128- or 256-column tiles
-#define QL_TILE_LIST_ROPE(X) X(1, 4, 2, 16, false) X(1, 4, 1, 4, true) X(2, 4, 2, 4, true) X(2, 4, 1, 4, true) X(4, 8, 1, 4, true)
+#define QL_TILE_LIST_ROPE(X) X(1, 4, 2, 16, false) X(1, 4, 1, 4, true) X(2, 4, 2, 4, true) X(2, 4, 1, 4, true) X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these
 template <int ACT, bool FP8W, bool GROUP>

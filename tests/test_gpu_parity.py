@@ -386,7 +386,7 @@ def _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, want_kv, quanti
     return outs
 
 
-ROPE_TILES = [(1, 4, 2, 16), (1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4), (4, 8, 1, 4)]    # QL_TILE_LIST_ROPE
+ROPE_TILES = [(1, 4, 2, 16), (1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4), (4, 8, 1, 2), (4, 8, 1, 4)]    # QL_TILE_LIST_ROPE
 
 
 @pytest.mark.parametrize("tile", ROPE_TILES)
