@@ -219,6 +219,20 @@ int ql_qknorm_rope_store(const void* qkv_bf16, const int64_t* positions, const f
  * the smallest index among equal maxima.  V % 8 == 0. */
 int ql_argmax_rows(const void* logits_bf16, int64_t* out, int64_t T, int64_t V, void* stream);
 
+/* Output projection (ParallelLMHead.forward, nanovllm/layers/embed_head.py:56-66 without the gather: the caller
+ * passes the rows it wants logits for): logits[M, V] = bf16(x[M, K] @ w[V, K]^T), bf16 operands (the table is the
+ * unquantized embedding matrix, as in the reference), f32 accumulation.  K % 32 == 0. */
+int ql_lmhead_logits(const void* x_bf16, const void* w_bf16, void* logits_bf16, int64_t M, int64_t V, int64_t K,
+                     void* stream);
+
+/* The same projection with the greedy sampler (nanovllm/layers/sampler.py:10-12) in its epilogue:
+ * tokens[m] = ql_argmax_rows(ql_lmhead_logits(x, w))[m], bit for bit (same kernel arithmetic, same tie and NaN
+ * rules), without the logits ever reaching memory.  workspace: at least ql_lmhead_workspace_bytes(M, V) bytes of
+ * device memory, need not be cleared. */
+size_t ql_lmhead_workspace_bytes(int64_t M, int64_t V);
+int ql_lmhead_argmax(const void* x_bf16, const void* w_bf16, int64_t* tokens, int64_t M, int64_t V, int64_t K,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Prefill attention: causal self-attention over packed variable-length sequences, the
  * flash_attn_varlen_func call of Attention.forward's prefill branch without a prefix cache
  * (nanovllm/layers/attention.py:64-69).  q [T,Hq,128], k/v [T,Hkv,128], out [T,Hq,128] bf16;

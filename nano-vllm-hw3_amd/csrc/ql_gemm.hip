@@ -25,7 +25,7 @@ static bool rope_tile_built(int mt, int wn, int wk, int cp) {
     return false;
 }
 
-struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; };
+struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; bool pair_rows = false; };
 
 static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false, bool rope = false) {
     Plan pl;
@@ -186,6 +186,7 @@ static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_byte
     // XCD-aware tile order for grids of many tiles per XCD (prefill): the XCD grouping along N that keeps an
     // XCD's weight slice within about half of its 4 MiB L2
     p.swz_gn = 0;
+    p.ntile_n = (int)pl.grid.x;
     static const bool no_swizzle = getenv("QL_NO_XCD_SWIZZLE") != nullptr;    // read once, not per launch
     if (pl.split == 1 && pl.grid.x * pl.grid.y >= 512 && !no_swizzle) {
         const uint64_t wbytes = (uint64_t)p.N * p.K;
@@ -195,7 +196,12 @@ static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_byte
             if (wbytes / gn <= (2u << 20)) break;
         }
     }
-    hipLaunchKernelGGL(k, pl.grid, dim3(64 * pl.wn * pl.wk), 0, s, p);
+    dim3 grid = pl.grid;
+    if (pl.pair_rows && pl.grid.y > 1 && pl.grid.y <= 8 && pl.split == 1) {
+        p.swz_gn = -(int)pl.grid.y;
+        grid = dim3((pl.grid.x + 7) / 8 * 8 * pl.grid.y, 1, 1);
+    }
+    hipLaunchKernelGGL(k, grid, dim3(64 * pl.wn * pl.wk), 0, s, p);
     QL_CHECK_LAUNCH(fn);
     return QL_OK;
 }
@@ -230,7 +236,7 @@ size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int gran
 
 int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
     const bool any = mt > 0 || wn > 0 || wk > 0 || cp > 0;
-    if (any && !tile_built(mt, wn, wk, cp, false)) {
+    if (any && !tile_built(mt, wn, wk, cp, false) && !pick_head(mt, wn, wk, cp, false)) {
         set_error("ql_gemm_force_config: tile (mt=%d, wn=%d, wk=%d, cp=%d) not built", mt, wn, wk, cp);
         return QL_EINVAL;
     }
@@ -441,6 +447,112 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
                       void* y, int64_t M, int64_t N, int64_t K, void* stream) {
     return gemm_w8a8("ql_gemm_w8a8_silu", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream);
+}
+
+// ---- output projection: bf16 activations x the bf16 embedding table, logits or the greedy sampler's tokens ----------
+// One row tile covers the step's sequences wherever it can (the table is then streamed from HBM once): 32, 64 or
+// 128 rows x 128 columns, 256 rows x 256 columns (eight waves, 64-k chunks); beyond 256 rows, 128 x 256 tiles whose
+// row tiles run side by side on one XCD.  Every workgroup runs the whole K.  Measured with tools/bench_lmhead.py.
+static Plan make_plan_head(int64_t M, int64_t V, int64_t K) {
+    Plan pl;
+    int mt = M <= 32 ? 1 : M <= 64 ? 2 : M <= 128 ? 4 : M <= 256 ? 8 : 4, wn = M <= 128 ? 4 : 8, wk = 1, cp = (M > 128 && M <= 256) ? 2 : 4;
+    pl.pair_rows = true;
+    if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && pick_head(f_mt, f_wn, f_wk, f_cp, false)) {
+        mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
+    }
+    pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
+    const int kb = 32 * cp * wk;
+    pl.split = 1;
+    pl.k_per_split = (int)((K + kb - 1) / kb * kb);
+    pl.grid = dim3((unsigned)((V + 32 * wn - 1) / (32 * wn)), (unsigned)((M + 32 * mt - 1) / (32 * mt)), 1);
+    return pl;
+}
+
+static int head_common(const char* fn, const void* x, const void* w, int64_t M, int64_t V, int64_t K) {
+    if (M < 0 || V <= 0 || K <= 0 || (M > 0 && (!x || !w))) { set_error("%s: bad argument", fn); return QL_EINVAL; }
+    if (K % 32) { set_error("%s: K=%lld must be a multiple of 32", fn, (long long)K); return QL_ESHAPE; }
+    // 32-bit byte offsets from the operand bases
+    if (V > 0x3FFFFFFF || (M + 255) / 32 > 65535 || (uint64_t)V * (uint64_t)K * 2 >= (1ull << 32) ||
+        (uint64_t)(M + 256) * (uint64_t)K * 2 >= (1ull << 32)) {
+        set_error("%s: shape too large", fn);
+        return QL_ESHAPE;
+    }
+    return QL_OK;
+}
+
+static GemmParams head_params(const void* x, const void* w, int64_t M, int64_t V, int64_t K) {
+    GemmParams p{};
+    p.x = (const unsigned char*)x;
+    p.w = (const unsigned char*)w;
+    p.M = (int)M; p.N = (int)V; p.K = (int)K;
+    p.sw_stride = 0;
+    return p;
+}
+
+namespace ql {
+// rows of {f32 bits of a maximum, its column} pairs, one pair per column tile -> the row's token
+__global__ __launch_bounds__(256) void argmax_finish_kernel(const int2* __restrict__ part, int ntiles, int64_t* __restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int2* row = part + (size_t)blockIdx.x * ntiles;
+    float best = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        const int2 e = row[t];
+        const float v = __builtin_bit_cast(float, e.x);
+        if (v > best || (v == best && e.y < bi)) { best = v; bi = e.y; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        out[blockIdx.x] = (bi == 0x7FFFFFFF) ? 0 : bi;
+    }
+}
+}  // namespace ql
+
+int ql_lmhead_logits(const void* x, const void* w, void* logits, int64_t M, int64_t V, int64_t K, void* stream) {
+    const char* fn = "ql_lmhead_logits";
+    if (int rc = head_common(fn, x, w, M, V, K)) return rc;
+    if (M > 0 && !logits) { set_error("%s: bad argument", fn); return QL_EINVAL; }
+    if (M == 0) return QL_OK;
+    const Plan pl = make_plan_head(M, V, K);
+    GemmParams p = head_params(x, w, M, V, K);
+    p.y = (unsigned short*)logits;
+    return run(pick_head(pl.mt, pl.wn, pl.wk, pl.cp, false), p, pl, nullptr, 0, as_stream(stream), fn);
+}
+
+size_t ql_lmhead_workspace_bytes(int64_t M, int64_t V) {
+    if (M <= 0 || V <= 0) return 0;
+    return (size_t)M * (size_t)((V + 127) / 128) * sizeof(int2);       // (128 columns: the narrowest tile)
+}
+
+int ql_lmhead_argmax(const void* x, const void* w, int64_t* tokens, int64_t M, int64_t V, int64_t K, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    const char* fn = "ql_lmhead_argmax";
+    if (int rc = head_common(fn, x, w, M, V, K)) return rc;
+    if (M > 0 && !tokens) { set_error("%s: bad argument", fn); return QL_EINVAL; }
+    if (M == 0) return QL_OK;
+    const Plan pl = make_plan_head(M, V, K);
+    const size_t need = (size_t)M * pl.grid.x * sizeof(int2);
+    if (!workspace || workspace_bytes < need) {
+        set_error("%s: workspace of %zu bytes needed, got %zu", fn, need, workspace_bytes);
+        return QL_EWORKSPACE;
+    }
+    GemmParams p = head_params(x, w, M, V, K);
+    p.amax = (int2*)workspace;
+    if (int rc = run(pick_head(pl.mt, pl.wn, pl.wk, pl.cp, true), p, pl, nullptr, 0, as_stream(stream), fn)) return rc;
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)M), dim3(256), 0, as_stream(stream), (const int2*)workspace,
+                       (int)pl.grid.x, tokens);
+    QL_CHECK_LAUNCH(fn);
+    return QL_OK;
 }
 
 }  // extern "C"

@@ -40,8 +40,8 @@ constexpr int kMaxTiles = kCounterBytes / 4;
 
 struct GemmParams {
     const unsigned char* x;      // [M,K] bf16 (ACT_BF16) or 1-byte (ACT_I8 / ACT_FP8)
-    const unsigned char* w;      // [N,K] 1-byte
-    const float* sw;             // [N] | [1] | [N, K/group]
+    const unsigned char* w;      // [N,K] 1-byte (W16 kernels: [N,K] bf16, row-major, no scales)
+    const float* sw;             // [N] | [1] | [N, K/group] (W16 kernels: null)
     const float* sx;             // [M] for W8A8, else null
     const unsigned short* bias;  // [N] bf16 or null
     unsigned short* y;           // [M,N] bf16
@@ -55,8 +55,13 @@ struct GemmParams {
     int k_per_split;             // multiple of the block's K chunk
     int bias_after_round;        // 1: bf16(bf16(v) + b)   0: bf16(v + b)
     int silu;                    // 1: weight rows alternate 32-row strips of gate and up; y[M, N/2] = silu(gate) * up
-    int swz_gn;                  // 0, or the number of XCD groups along N (1, 2, 4, 8) of the XCD-aware tile order
+    int swz_gn;                  // 0, or the number of XCD groups along N (1, 2, 4, 8) of the XCD-aware tile order,
+                                 // or -R: a 1-D grid in which the R row tiles of a column tile are 8 workgroup ids apart
+    int ntile_n;                 // column tiles (the grid's x extent unless swz_gn < 0)
     int wtiled;                  // 1: w is stored as [N/32 strips][K/32 steps][64 lanes][16 bytes] (see ql_tile_weight)
+    int2* amax;                  // AMAX kernels (output projection with the greedy sampler in the epilogue): y is not
+                                 // stored; [M][gridDim.x] pairs {f32 bits of the row's maximum over the tile's columns as
+                                 // the bf16 the plain kernel would store, its smallest column}, reduced by argmax_finish
     int rope_on;                 // 1 on the ROPE kernels (qkv projection: y is not stored; q/k norm + RoPE + KV store in the epilogue)
     RopeArgs rope;
 };
@@ -95,6 +100,9 @@ __device__ __forceinline__ bf16x8 widen8(int d0, int d1) {
     i32x4 v = {(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
+
+// what one 32-k step of a lane's weight column occupies: 16 one-byte weights, or (W16) 16 bf16 in two registers sets
+struct W2 { i32x4 a, b; };
 
 // 16-byte load through an explicitly GLOBAL pointer: pointers that arrive inside the by-value parameter struct
 // are generic to the compiler, and a generic (flat) load also counts against lgkmcnt, so every LDS wait in the
@@ -140,9 +148,13 @@ struct Cfg {
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP, bool ROPE = false>
+template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP, bool ROPE = false, bool W16 = false,
+          bool AMAX = false>
 __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p) {
     static_assert(!ROPE || WN == 4 || WN == 8, "the qkv epilogue needs whole 128-column heads per workgroup");
+    static_assert(!W16 || (ACT == ACT_BF16 && !GROUP && !ROPE && !FP8W), "16-bit weights: plain bf16 x bf16");
+    static_assert(!AMAX || (W16 && WK == 1 && WN >= 4), "the sampler epilogue is built for the output projection's tiles");
+    using wreg_t = typename std::conditional<W16, W2, i32x4>::type;
     using C = Cfg<ACT, MT, WN, WK, CP, DB>;
     constexpr bool INT = (ACT == ACT_I8);
     constexpr int RB = C::RB;
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     using raw_t = typename std::conditional<INT, int, float>::type;
     using TrueT = std::integral_constant<bool, true>;
     using FalseT = std::integral_constant<bool, false>;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[ROPE ? C::LDS_ROPE : C::LDS];   // base must be a multiple of 32 (address ^ 16 below)
+    __shared__ __attribute__((aligned(128))) unsigned char smem[(ROPE || AMAX) ? C::LDS_ROPE : C::LDS];   // base must be a multiple of 32 (address ^ 16 below)
 
     // The kernel is VALU-issue-bound at decode sizes, so everything that is uniform per wave is kept
     // in scalar registers (the wave index is made provably uniform) and every per-lane address is
@@ -172,7 +184,15 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // walks its N tiles fastest, so concurrent workgroups share an activation tile in L2 and the XCD's slice of
     // the weights (N*K/gn bytes) stays L2-resident.
     unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (p.swz_gn > 0) {          // host guarantees gridDim.x % gn == 0, gridDim.y % (8 / gn) == 0, gridDim.z == 1
+    if (p.swz_gn < 0) {
+        // Few row tiles over a long weight stream (the output projection at 129+ rows): workgroup ids are dealt
+        // round-robin over the XCDs, so ids 8 apart run on the same XCD at about the same time; giving them the
+        // same column tile makes the second row tile's weight reads L2 hits instead of a second pass over HBM.
+        const unsigned R = (unsigned)-p.swz_gn, lin = blockIdx.x;
+        bx = (lin / (8u * R)) * 8u + (lin & 7u);
+        by = (lin >> 3) % R;
+        if (bx >= (unsigned)p.ntile_n) return;               // (the grid is padded to whole groups of 8 R)
+    } else if (p.swz_gn > 0) {          // host guarantees gridDim.x % gn == 0, gridDim.y % (8 / gn) == 0, gridDim.z == 1
         const unsigned lin = by * gridDim.x + bx, xcd = lin & 7u, idx = lin >> 3;
         const unsigned gn = (unsigned)p.swz_gn, gm = 8u / gn, ntl = gridDim.x / gn;
         bx = (xcd % gn) * ntl + idx % ntl;
@@ -190,10 +210,12 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // Row-major weights: lane (column l31, k half lh) reads 16 bytes of its own row - 32 rows per wave load,
     // 32 bytes used of every 128-byte line touched.  Tiled weights: the 32 columns x 32 k of one wave load are
     // stored as one contiguous KiB in lane order, so a load touches 8 full lines instead of 32 partial ones.
-    const unsigned kmul = p.wtiled ? 32u : 1u;                    // bytes the load address advances per k
+    // (W16: row-major only; the lane's 16 k of a step are 32 contiguous bytes)
+    const unsigned kmul = W16 ? 2u : (p.wtiled ? 32u : 1u);       // bytes the load address advances per k
     // (a strip past the last one re-reads the last strip, like the clamped row above: never stored)
     const unsigned wstrip = min((unsigned)(n0 >> 5), (unsigned)((p.N + 31) / 32 - 1));
-    const unsigned woff = p.wtiled ? wstrip * (unsigned)p.K * 32u + (unsigned)lane * 16u
+    const unsigned woff = W16 ? (unsigned)nrow * (unsigned)p.K * 2u + (unsigned)(32 * lh)
+                        : p.wtiled ? wstrip * (unsigned)p.K * 32u + (unsigned)lane * 16u
                                    : (unsigned)nrow * (unsigned)p.K + (unsigned)(16 * lh);   // + uniform k offset per load
 
     // activation staging: thread t moves piece ci = t % CPR of rows row0 + j * RS (j < NP)
@@ -241,15 +263,20 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // ahead.  Every chunk ends on a workgroup barrier behind the slowest of its 4096 16-byte requests, and with long
     // K slices one chunk of lead does not cover that tail; a second register set per operand buys a second chunk of
     // lead, while two LDS buffers still suffice.
-    constexpr bool DEEP = DB && WN == 8 && ACT == ACT_BF16;
-    i32x4 wcur[D], wnext[(DB && WN != 8) ? CP : 1], sreg[C::NP];
-    i32x4 wcur2[DEEP ? CP : 1], sreg2[DEEP ? C::NP : 1];
+    constexpr bool DEEP = DB && WN == 8 && ACT == ACT_BF16 && !W16;
+    wreg_t wcur[D], wnext[(DB && WN != 8) ? CP : 1], wcur2[DEEP ? CP : 1];
+    i32x4 sreg[C::NP], sreg2[DEEP ? C::NP : 1];
 
     // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
-    auto load_w1 = [&](auto chk, int kc, int c) -> i32x4 {
+    auto load_w_at = [&](int kb) -> wreg_t {
+        if constexpr (W16) return W2{gload16(p.w + kb * kmul + woff), gload16(p.w + kb * kmul + woff + 16)};
+        else return gload16(p.w + kb * kmul + woff);
+    };
+    auto load_w1 = [&](auto chk, int kc, int c) -> wreg_t {
         const int kb = kc + wk * C::KW + c * 32;
-        if (!decltype(chk)::value || kb < kend) return gload16(p.w + kb * kmul + woff);
-        return i32x4{0, 0, 0, 0};
+        if (!decltype(chk)::value || kb < kend) return load_w_at(kb);
+        if constexpr (W16) return W2{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+        else return i32x4{0, 0, 0, 0};
     };
     auto load_x_to = [&](auto chk, int kc, i32x4* sreg) {
         if (fullM) {
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             }
     };
     // one 32-k step of this wave: widen the 16 weight bytes of the lane, MT x (A fragment reads + MFMAs)
-    auto step = [&](auto chk, int buf, int kc, int c, const i32x4 w) {
+    auto step = [&](auto chk, int buf, int kc, int c, const wreg_t w) {
         const int kb = kc + wk * C::KW + c * 32;   // first k of this step (wave-uniform)
         if (decltype(chk)::value && kb >= kend) return;
         const int base_c = (wk * CP + c) * APS;    // first piece of the step in an LDS row (uniform)
@@ -298,8 +325,14 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         // (an integer), not a pointer: xor-ing a pointer through uintptr_t makes it generic and the read a flat load
         const int a0 = buf * C::XBYTES + a_row + ((base_c & ~SWZ_MASK) << 4) + (((base_c & SWZ_MASK) << 4) ^ a_g4);
         if constexpr (ACT == ACT_BF16) {
-            const bf16x8 blo = widen8<FP8W>(w[0], w[1]);
-            const bf16x8 bhi = widen8<FP8W>(w[2], w[3]);
+            bf16x8 blo, bhi;
+            if constexpr (W16) {
+                blo = __builtin_bit_cast(bf16x8, w.a);
+                bhi = __builtin_bit_cast(bf16x8, w.b);
+            } else {
+                blo = widen8<FP8W>(w[0], w[1]);
+                bhi = widen8<FP8W>(w[2], w[3]);
+            }
             const int a1 = a0 ^ 16;                                // piece index + 1 == ^1 (index is even)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -345,9 +378,9 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // without spilling (+8-10 % at M = 16384 over 64-k chunks).  The address is clamped into the slice instead
     // of branching around the load (past the end the last step is re-read and never used: step() skips it).
     constexpr bool RING = DB && WN == 8;
-    auto load_w_ring = [&](int kc, int c) -> i32x4 {
+    auto load_w_ring = [&](int kc, int c) -> wreg_t {
         const int kb = min(kc + wk * C::KW + c * 32, kend - 32);
-        return gload16(p.w + kb * kmul + woff);
+        return load_w_at(kb);
     };
     auto chunk_db = [&](auto chk, int it) {
         const int kc = k0 + it * C::KB;
@@ -357,7 +390,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             if (more) load_x(TrueT{}, kc + C::KB);
 #pragma unroll
             for (int c = 0; c < CP; ++c) {
-                const i32x4 w = wcur[c];
+                const wreg_t w = wcur[c];
                 wcur[c] = load_w_ring(kc + C::KB, c);
                 step(chk, buf, kc, c, w);
             }
@@ -383,11 +416,11 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     auto chunk_deep = [&](auto chk, auto par, int it) {
         constexpr int PAR = decltype(par)::value;
         const int kc = k0 + it * C::KB;
-        i32x4* wset = PAR ? wcur2 : wcur;
+        wreg_t* wset = PAR ? wcur2 : wcur;
         if (it + 2 < nchunks) load_x_to(TrueT{}, kc + 2 * C::KB, PAR ? sreg2 : sreg);
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
-            const i32x4 w = wset[c];
+            const wreg_t w = wset[c];
             wset[c] = load_w_ring(kc + 2 * C::KB, c);
             step(chk, PAR, kc, c, w);
         }
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         for (int c0 = 0; c0 < CP; c0 += D) {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const i32x4 w = wcur[j];
+                const wreg_t w = wcur[j];
                 if (c0 + D + j < CP) wcur[j] = load_w1(chk, kc, c0 + D + j);
                 step(chk, 0, kc, c0 + j, w);
             }
@@ -476,7 +509,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     const int n = n0 + l31;
     const bool nvalid = n < p.N;
     float sw = 1.f, bias = 0.f;
-    if (!GROUP && nvalid) sw = p.sw[(size_t)n * p.sw_stride];
+    if (!GROUP && !W16 && nvalid) sw = p.sw[(size_t)n * p.sw_stride];
     const bool has_bias = p.bias != nullptr;
     if (has_bias && nvalid) bias = bf16_bits_to_f32(p.bias[n]);
 
@@ -615,6 +648,47 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             }
             return;
         }
+        if constexpr (AMAX) {
+            // output projection with the greedy sampler in the epilogue: the bf16 values the plain kernel would store
+            // go to an LDS image; BN / 8 lanes per row then find the row's maximum over the tile's columns (smallest
+            // column among equal maxima, NaN never wins: the rules of argmax_rows_kernel) and one of them stores it
+            __syncthreads();                                  // every wave is done with the x tile
+            unsigned short* img = (unsigned short*)smem;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int rr = 0; rr < RN; ++rr) {
+                    const int r = R0 + rr;
+                    const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);
+                    img[(rowc + 4 * lh) * C::ROPE_RS + wn * 32 + l31] = __builtin_bit_cast(unsigned short, outv(i, r, rowc));
+                }
+            __syncthreads();
+            constexpr int PPR = C::BN / 8;                    // lanes per row: 16 or 32, an aligned part of one wave
+            static_assert((C::BM * PPR) % C::NT == 0 && 64 % PPR == 0, "whole lane groups, all threads in every pass");
+            const int col0 = (int)(bx * C::BN);
+#pragma unroll
+            for (int idx = tid; idx < C::BM * PPR; idx += C::NT) {
+                const int row = idx / PPR, pc = idx % PPR;
+                const u16x8 a = *(const u16x8*)(img + row * C::ROPE_RS + pc * 8);
+                float best = -INFINITY;
+                int bi = 0x7FFFFFFF;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = bf16_bits_to_f32(a[k]);
+                    const int col = col0 + pc * 8 + k;
+                    if (col < p.N && v > best) { best = v; bi = col; }
+                }
+#pragma unroll
+                for (int o = PPR / 2; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bi, o);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                if (pc == 0 && m0 + row < p.M)
+                    p.amax[(size_t)(m0 + row) * p.ntile_n + bx] = int2{__builtin_bit_cast(int, best), bi};
+            }
+            return;
+        }
         if constexpr (ROPE) {
             {
                 // qkv projection with the q/k norm + RoPE + KV-cache store in the epilogue: the tile's columns are
@@ -696,6 +770,17 @@ struct TileCfg { int mt, wn, wk, cp, db; };
 #define QL_TILE_LIST_ROPE(X) X(1, 4, 2, 16, false) X(1, 4, 1, 4, true) X(2, 4, 2, 4, true) X(2, 4, 1, 4, true) X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)
 
 // one translation unit per arithmetic variant instantiates these
+// The output projection (bf16 weights shared with the embedding table, vocabulary-sized N, M = sequences of a step)
+#define QL_TILE_LIST_HEAD(X) X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true) X(4, 8, 1, 4, true) X(8, 8, 1, 2, true)
+template <bool AMAX>
+kern_t pick_head_impl(int mt, int wn, int wk, int cp) {
+#define QL_PICK_HEAD(MT_, WN_, WK_, CP_, DB_) \
+    if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) return (kern_t)qgemm_kernel<ACT_BF16, false, MT_, WN_, WK_, CP_, DB_, false, false, true, AMAX>;
+    QL_TILE_LIST_HEAD(QL_PICK_HEAD)
+#undef QL_PICK_HEAD
+    return nullptr;
+}
+
 template <int ACT, bool FP8W, bool GROUP>
 kern_t pick_kernel_impl(int mt, int wn, int wk, int cp, bool rope) {
     if (rope) {
@@ -725,5 +810,6 @@ kern_t pick_bf16_fp8_row(int, int, int, int, bool rope = false);
 kern_t pick_bf16_fp8_group(int, int, int, int, bool rope = false);
 kern_t pick_i8_i8(int, int, int, int, bool rope = false);
 kern_t pick_fp8_fp8(int, int, int, int, bool rope = false);
+kern_t pick_head(int, int, int, int, bool amax);
 
 }  // namespace ql

@@ -54,6 +54,9 @@ SIGNATURES = {
     "ql_qknorm_rope_store": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),
     "ql_argmax_rows": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    "ql_lmhead_logits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ql_lmhead_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "ql_lmhead_argmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
     "ql_attn_prefill": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                                  _c_int, _c_vp]),
     "ql_paged_attn_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
@@ -158,3 +161,4 @@ class _Workspace:
 
 workspace = _Workspace()        # split-K slabs of the GEMMs
 attn_workspace = _Workspace()   # per-KV-block partial states of decode attention
+head_workspace = _Workspace()   # per-column-tile row maxima of the output projection's sampler epilogue

@@ -63,6 +63,7 @@ class ModelRunner:
                 from nanovllm import _qlinear
                 _qlinear.workspace.pin(self.device)        # the graphs address these buffers: never freed
                 _qlinear.attn_workspace.pin(self.device)
+                _qlinear.head_workspace.pin(self.device)
         finally:
             torch.set_default_device("cpu")
             torch.set_default_dtype(default_dtype)
@@ -232,12 +233,17 @@ class ModelRunner:
         ``prev`` = handle of the decode step before this one when its tokens have not been read on the host
         yet: the input ids of this step are then gathered on the device from that step's output (every
         sequence of this step must have been part of it), so the host never waits between two steps."""
+        tokens = logits = None
         if is_prefill:
             assert prev is None
             ids, pos, cu = self.prepare_prefill(seqs)
             h = self.model(ids, pos)
             last = torch.tensor(cu[1:], device=self.device) - 1
-            logits = self.model.compute_logits(h[last].contiguous())
+            rows = h[last].contiguous()
+            if self.on_gpu and self.model.lm_head.fused_sampler(rows):
+                tokens = self.model.compute_tokens(rows)          # sampler in the projection's epilogue
+            else:
+                logits = self.model.compute_logits(rows)
         else:
             perm = None
             if prev is not None:
@@ -249,16 +255,27 @@ class ModelRunner:
                 torch.index_select(prev["tokens"], 0, self._dv[5][:bs], out=ids)
             if self.enforce_eager or bs > self.max_graph_bs:
                 set_context(AttnContext(False, None, slots, ctx_lens, tables))
-                logits = self.model.compute_logits(self.model(ids, pos))
+                h = self.model(ids, pos)
+                if self.on_gpu and self.model.lm_head.fused_sampler(h):
+                    tokens = self.model.compute_tokens(h)
+                else:
+                    logits = self.model.compute_logits(h)
             else:
                 gbs = next(x for x in self.graph_bs if x >= bs)
                 gv = self.graph_vars
                 self.graphs[gbs].replay()
-                logits = gv["logits"][:bs]
+                if "tokens" in gv:
+                    # the graph's own buffer: its readers (the copy to the host below, the gather into the next
+                    # step's input ids) are enqueued on this stream before the next replay overwrites it
+                    tokens = gv["tokens"][:bs]
+                else:
+                    logits = gv["logits"][:bs]
         # greedy sampler (layers/sampler.py:10-12)
         if not self.on_gpu:
             return dict(seqs=list(seqs), tokens=logits.float().argmax(dim=-1), host=None, event=None)
-        if logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0 and logits.is_contiguous():
+        if tokens is not None:
+            pass
+        elif logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0 and logits.is_contiguous():
             from nanovllm import ops
             tokens = ops.argmax_rows(logits)
         else:
@@ -270,6 +287,7 @@ class ModelRunner:
             host.copy_(tokens, non_blocking=True)
         else:
             host = None
+            tokens = tokens.clone()          # read at wait(): must not alias a buffer a later step rewrites
         ev = torch.cuda.Event()
         ev.record()
         return dict(seqs=list(seqs), tokens=tokens, host=host, event=ev)
@@ -296,17 +314,32 @@ class ModelRunner:
         max_blocks = (cfg.max_model_len + self.block_size - 1) // self.block_size
         d = self._dv
         assert self._stage_max_bs >= max_bs and self._stage_max_blocks >= max_blocks
-        gv = dict(input_ids=d[0], positions=d[1], slot_mapping=d[2], context_lens=d[3], block_tables=d[4],
-                  logits=torch.zeros(max_bs, hf.vocab_size))
+        gv = dict(input_ids=d[0], positions=d[1], slot_mapping=d[2], context_lens=d[3], block_tables=d[4])
+        probe = torch.zeros(1, hf.hidden_size)
+        fused = self.model.lm_head.fused_sampler(probe)
+        if fused:
+            gv["tokens"] = torch.zeros(max_bs, dtype=torch.int64)     # the graphs end in the sampler
+            from nanovllm import ops
+            ops.reserve_head_workspace(max_bs, self.model.lm_head.weight.shape[0], self.device)
+        else:
+            gv["logits"] = torch.zeros(max_bs, hf.vocab_size)
+
+        def step(bs):
+            h = self.model(gv["input_ids"][:bs], gv["positions"][:bs])
+            if fused:
+                self.model.compute_tokens(h, out=gv["tokens"][:bs])
+            else:
+                gv["logits"][:bs] = self.model.compute_logits(h)
+
         self.graph_bs = [1, 2, 4, 8] + list(range(16, max_bs + 1, 16))
         pool = None
         for bs in reversed(self.graph_bs):
             set_context(AttnContext(False, None, gv["slot_mapping"][:bs], gv["context_lens"][:bs], gv["block_tables"][:bs]))
-            gv["logits"][:bs] = self.model.compute_logits(self.model(gv["input_ids"][:bs], gv["positions"][:bs]))  # warm-up
+            step(bs)                                                  # warm-up
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool):
-                gv["logits"][:bs] = self.model.compute_logits(self.model(gv["input_ids"][:bs], gv["positions"][:bs]))
+                step(bs)
             if pool is None:
                 pool = g.pool()
             self.graphs[bs] = g

@@ -36,6 +36,9 @@ _CTX = AttnContext()
 # separate operator on the same tile; NANOVLLM_NO_QKV_ROPE=1 keeps the two launches, for A/B measurements)
 import os as _os
 FUSE_QKV_ROPE = _os.environ.get("NANOVLLM_NO_QKV_ROPE", "") == ""
+# The output projection runs on this package's bf16 GEMM, with the greedy sampler in its epilogue where the caller
+# only wants tokens (NANOVLLM_NO_HEAD_ARGMAX=1 keeps torch's GEMM and the separate argmax launch, for A/B measurements)
+FUSE_HEAD_ARGMAX = _os.environ.get("NANOVLLM_NO_HEAD_ARGMAX", "") == ""
 
 
 def set_context(ctx: AttnContext):
@@ -90,8 +93,26 @@ class ParallelLMHead(VocabParallelEmbedding):
         super().__init__(num_embeddings, embedding_dim)
         self.quantized = None     # a per-row W8A16 QLinear over this rank's vocabulary shard (opt-in: quantize_lm_head)
 
+    def fused_sampler(self, x):
+        """True when greedy_tokens(x) can run: bf16 table on this GPU, no vocabulary sharding, K a multiple of 32."""
+        return (FUSE_HEAD_ARGMAX and self.quantized is None and self.tp_size == 1 and x.is_cuda and
+                x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and x.shape[-1] % 32 == 0)
+
+    def greedy_tokens(self, x, out=None):
+        """argmax(forward(x), -1) without the logits reaching memory: the sampler (layers/sampler.py:10-12) runs in
+        the projection's epilogue; bit-identical to ops.argmax_rows(ops.lm_head_logits(x, weight))."""
+        from nanovllm import ops
+        return ops.lm_head_argmax(x, self.weight, out=out)
+
     def forward(self, x):
-        logits = F.linear(x, self.weight) if self.quantized is None else self.quantized(x)
+        if self.quantized is not None:
+            logits = self.quantized(x)
+        elif FUSE_HEAD_ARGMAX and x.is_cuda and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 \
+                and x.dim() == 2 and x.shape[0] <= 1024 and x.shape[-1] % 32 == 0:
+            from nanovllm import ops
+            logits = ops.lm_head_logits(x.contiguous(), self.weight)      # (the kernel greedy_tokens shares)
+        else:
+            logits = F.linear(x, self.weight)
         if self.tp_size > 1:
             if dist.get_backend() == "gloo" and logits.is_cuda:     # test transport: gloo moves host memory
                 host = logits.cpu()
@@ -241,3 +262,7 @@ class Qwen3ForCausalLM(nn.Module):
 
     def compute_logits(self, hidden_states):
         return self.lm_head(hidden_states)
+
+    def compute_tokens(self, hidden_states, out=None):
+        """Greedy tokens of the given rows; the caller checks lm_head.fused_sampler(hidden_states) first."""
+        return self.lm_head.greedy_tokens(hidden_states, out=out)

@@ -143,6 +143,42 @@ def attn_prefill(q, k, v, cu_seqlens, max_seqlen, scale):
     return out
 
 
+def lm_head_logits(x, weight):
+    """bf16 logits [M, V] = x [M, K] @ weight [V, K]^T (f32 accumulation), the output projection of
+    ParallelLMHead.forward (nanovllm/layers/embed_head.py:61) on the rows the caller selected."""
+    Q.require_cuda(x, BF16, "x")
+    Q.require_cuda(weight, BF16, "weight")
+    M, K = x.shape
+    V = weight.shape[0]
+    assert weight.shape == (V, K)
+    out = torch.empty((M, V), dtype=BF16, device=x.device)
+    Q.check(Q.load().ql_lmhead_logits(x.data_ptr(), weight.data_ptr(), out.data_ptr(), M, V, K, Q.stream_ptr(x.device)))
+    return out
+
+
+def reserve_head_workspace(max_rows, vocab, device=None):
+    """Allocate the sampler epilogue's workspace for the largest step before graph capture."""
+    Q.head_workspace.reserve(device or "cuda", Q.load().ql_lmhead_workspace_bytes(max_rows, vocab))
+
+
+def lm_head_argmax(x, weight, out=None):
+    """Greedy tokens int64 [M] = argmax_rows(lm_head_logits(x, weight)) bit for bit, the sampler running in the
+    projection's epilogue: the logits are never written (embed_head.py:61 + layers/sampler.py:10-12)."""
+    Q.require_cuda(x, BF16, "x")
+    Q.require_cuda(weight, BF16, "weight")
+    M, K = x.shape
+    V = weight.shape[0]
+    assert weight.shape == (V, K)
+    if out is None:
+        out = torch.empty((M,), dtype=torch.int64, device=x.device)
+    assert out.dtype == torch.int64 and out.numel() == M and out.is_contiguous()
+    lib = Q.load()
+    ws, nbytes = Q.head_workspace.get(x.device, lib.ql_lmhead_workspace_bytes(M, V))
+    Q.check(lib.ql_lmhead_argmax(x.data_ptr(), weight.data_ptr(), out.data_ptr(), M, V, K, ws, nbytes,
+                                 Q.stream_ptr(x.device)))
+    return out
+
+
 def argmax_rows(logits):
     """Greedy sampling: int64 [T] = argmax over the last dim of bf16 logits [T, V] (first index among ties)."""
     Q.require_cuda(logits, BF16, "logits")

@@ -13,11 +13,20 @@ REPS = 5
 
 
 def run():
+    """The four linears as the decode graph launches them: qkv with the q/k norm + RoPE + KV-store epilogue, gate/up
+    with the SiLU epilogue, o_proj / down_proj with the split-K reduction deferred wherever the plan defers it."""
+    import types
     import torch
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(ROOT, "nano-vllm-hw3_amd"))
+    from nanovllm import _qlinear as Q
     from nanovllm.utils import quantization as NQ
+    lib = Q.load()
     torch.manual_seed(0)
+    cos_sin = torch.randn(4096, 128, device="cuda", dtype=torch.float32)
+    nw = torch.ones(128, device="cuda", dtype=torch.bfloat16)
+    kc = torch.zeros(2, 256, 8, 128, device="cuda", dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
     for name, N, K in SHAPES:
         ws = []
         for _ in range(REPS):
@@ -25,11 +34,21 @@ def run():
             q, s = NQ.per_row_quant(w, torch.int8)
             if name.endswith("silu"):
                 q, s = NQ.interleave_gate_up(q), NQ.interleave_gate_up(s)
-            ws.append((NQ.tile_weight(q), s))             # the layout the engine's modules use
+            # the layout the engine's modules use, behind the attributes the launch helpers read
+            ws.append(types.SimpleNamespace(qw=NQ.tile_weight(q), sw=s, dtype=torch.int8, _bias_for_rank=lambda: None))
         for M in MS:
             x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
-            for q, s in ws:
-                NQ.per_row_weight_only_matmul(x, q, s, None, torch.int8, silu=name.endswith("silu"))
+            pos = torch.randint(0, 4096, (M,), device="cuda")
+            slots = torch.arange(M, device="cuda", dtype=torch.int32)
+            for mod in ws:
+                if name == "qkv":
+                    NQ.qkv_rope_matmul(mod, x, pos, cos_sin, nw, nw, 1e-6, 16, 8, 128, kc, vc, slots, want_kv=False)
+                elif name.endswith("silu"):
+                    NQ.per_row_weight_only_matmul(x, mod.qw, mod.sw, None, torch.int8, silu=True)
+                elif M <= NQ._QBase.PARTIAL_MAX_ROWS and lib.ql_gemm_partial_slices(M, N, K, Q.QL_PER_ROW) > 1:
+                    NQ.w8a16_partial_matmul(mod, x)
+                else:
+                    NQ.per_row_weight_only_matmul(x, mod.qw, mod.sw, None, torch.int8)
                 torch.cuda.synchronize()          # one dispatch at a time: the counter pass drops records otherwise
 
 
@@ -39,7 +58,7 @@ def kernel_fingerprint():
     import hashlib
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nano-vllm-hw3_amd", "csrc")
     h = hashlib.sha256()
-    for f in ("ql_common.h", "ql_gemm_kernel.h", "ql_gemm.hip"):
+    for f in ("ql_common.h", "ql_rope.h", "ql_gemm_kernel.h", "ql_gemm.hip"):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()
 
