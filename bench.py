@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--quant-lm-head", action="store_true", help="opt-in int8 LM head (not the reference's numerics)")
     ap.add_argument("--max-model-len", type=int, default=4096, help="4096 = the reference bench; other values are experiments")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (ranks share devices)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -286,9 +288,9 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if args.backend == "nccl" else local % torch.cuda.device_count())
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from nanovllm import LLM, SamplingParams
     model_dir = tempfile.mkdtemp(prefix=f"qwen3_06b_r{rank}_")
@@ -300,7 +302,23 @@ def main():
                   group_size=128)
     if args.quant_lm_head:
         kw.update(quantize_lm_head=True)
-    llm = LLM(model_dir, **kw)
+    decode_mode = "hipGraph decode"
+    try:
+        llm = LLM(model_dir, **kw)
+    except Exception as ex:  # noqa: BLE001
+        if world == 1:
+            raise
+        # Tensor-parallel ranks only: a collective that this RCCL build cannot capture into a hipGraph fails the
+        # capture on every rank alike; the curve is then measured with eager decode steps, and the line says so.
+        print(f"[rank {rank}] graph capture failed ({type(ex).__name__}: {ex}); falling back to eager decode",
+              file=sys.stderr, flush=True)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        kw["enforce_eager"] = True
+        decode_mode = f"EAGER decode (graph capture failed: {type(ex).__name__})"
+        llm = LLM(model_dir, **kw)
 
     prompts, max_tokens = workload()
     sps = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m) for m in max_tokens]
@@ -337,9 +355,11 @@ def main():
         dt = float(t.item())
 
     roof = roof_prefill = None
-    if rank == 0 and not args.no_roofline and args.quant != "bf16":
+    # (one GPU only: under tensor parallelism the row-parallel modules' forward contains a collective, which one
+    # rank must not issue alone)
+    if rank == 0 and world == 1 and not args.no_roofline and args.quant != "bf16":
         roof = measure_decode_gemm(llm, step_batches[: len(step_batches) // max(args.steps, 1)])
-        roof_prefill = measure_prefill_gemm(llm) if world == 1 else None
+        roof_prefill = measure_prefill_gemm(llm)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -352,7 +372,7 @@ def main():
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "reference bench.py: 256 seqs, prompts 100-1024 random tokens, 100-1024 new tokens "
                                    "(133,966 output tokens), Qwen3-0.6B random-init, "
-                                   f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, hipGraph decode",
+                                   f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, {decode_mode}",
                        "parallelism": f"tp{world}", "decode_steps": len(step_batches) // max(args.steps, 1)},
             "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,
         }
