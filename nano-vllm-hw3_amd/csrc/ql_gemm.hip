@@ -59,6 +59,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
         const int64_t b128 = ((M + 31) / 32) * ((N + 127) / 128);
         if (b128 >= 176 && b128 <= 256) { mt = 1; wn = 4; wk = 2; cp = 16; }
     }
+    // the same on one round of 64 x 128 tiles (gate/up at 161..320 rows: -4..8 % against four 256-k chunks; with
+    // more tiles than CUs the chunked form wins again, -22 % at 512 rows)
+    if (pick == nladder - 1 && K == 1024 && ((M + 63) / 64) * ((N + 127) / 128) <= 256) cp = 16;
     // K up to 2048 on the 32 x 32 tile: one 2048-k chunk (the whole row of activations resident, no split, no
     // second staging round) measured 0.6 us faster than two 1024-k chunks or slices
     if (pick == 0 && K > 1024 && K <= 2048) cp = 8;
