@@ -161,7 +161,7 @@ def measure_decode_gemm(llm, step_batches):
                     at = layers[li].self_attn
                     ops.qknorm_rope_store(qkv_out, pos, at.cos_sin, at.q_norm.weight, at.k_norm.weight, at.eps, at.num_heads,
                                           at.num_kv_heads, at.head_dim, at.k_cache, at.v_cache, slots, want_kv=False)
-            def plain():                # the self-contained form of every launch (last round's methodology)
+            def plain():                # the self-contained form of every launch (every launch with its own reduction and a separate RoPE operator)
                 for m4 in mods:
                     for x, m in zip(xs, m4):
                         m(x)
@@ -191,7 +191,7 @@ def measure_decode_gemm(llm, step_batches):
                       "M = graph bucket)",
             "avg_launch_us": round(avg_us, 2),
             # the same launches without the norms that finish the deferred reductions (what a kernel trace shows
-            # for these kernels, plus the launch gap), their self-contained form (last round's methodology), and
+            # for these kernels, plus the launch gap), their self-contained form (every launch with its own reduction and a separate RoPE operator), and
             # the launches' cost net of the stand-alone RoPE operator their epilogue replaced
             "avg_launch_us_gemm_launches_only": round(tot_raw / tot_n * 1e6, 2),
             "avg_launch_us_self_contained_form": round(tot_plain / tot_n * 1e6, 2),

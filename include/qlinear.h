@@ -227,11 +227,13 @@ int ql_lmhead_logits(const void* x_bf16, const void* w_bf16, void* logits_bf16, 
 
 /* The same projection with the greedy sampler (nanovllm/layers/sampler.py:10-12) in its epilogue:
  * tokens[m] = ql_argmax_rows(ql_lmhead_logits(x, w))[m], bit for bit (same kernel arithmetic, same tie and NaN
- * rules), without the logits ever reaching memory.  workspace: at least ql_lmhead_workspace_bytes(M, V) bytes of
- * device memory, need not be cleared. */
+ * rules), without the logits ever reaching memory.  max_out (f32 [M], may be NULL) receives the winning logit
+ * (-inf for a row without a finite maximum): what vocabulary-parallel ranks exchange instead of the logits the
+ * reference gathers (embed_head.py:62-65).  workspace: at least ql_lmhead_workspace_bytes(M, V) bytes of device
+ * memory, need not be cleared. */
 size_t ql_lmhead_workspace_bytes(int64_t M, int64_t V);
-int ql_lmhead_argmax(const void* x_bf16, const void* w_bf16, int64_t* tokens, int64_t M, int64_t V, int64_t K,
-                     void* workspace, size_t workspace_bytes, void* stream);
+int ql_lmhead_argmax(const void* x_bf16, const void* w_bf16, int64_t* tokens, float* max_out, int64_t M, int64_t V,
+                     int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Prefill attention: causal self-attention over packed variable-length sequences, the
  * flash_attn_varlen_func call of Attention.forward's prefill branch without a prefix cache

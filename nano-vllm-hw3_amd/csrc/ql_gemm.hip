@@ -494,7 +494,8 @@ static GemmParams head_params(const void* x, const void* w, int64_t M, int64_t V
 
 namespace ql {
 // rows of {f32 bits of a maximum, its column} pairs, one pair per column tile -> the row's token
-__global__ __launch_bounds__(256) void argmax_finish_kernel(const int2* __restrict__ part, int ntiles, int64_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void argmax_finish_kernel(const int2* __restrict__ part, int ntiles, int64_t* __restrict__ out,
+                                                            float* __restrict__ max_out) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int2* row = part + (size_t)blockIdx.x * ntiles;
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(256) void argmax_finish_kernel(const int2* __restri
         for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
         out[blockIdx.x] = (bi == 0x7FFFFFFF) ? 0 : bi;
+        if (max_out) max_out[blockIdx.x] = best;              // -inf when the row has no finite maximum
     }
 }
 }  // namespace ql
@@ -537,8 +539,8 @@ size_t ql_lmhead_workspace_bytes(int64_t M, int64_t V) {
     return (size_t)M * (size_t)((V + 127) / 128) * sizeof(int2);       // (128 columns: the narrowest tile)
 }
 
-int ql_lmhead_argmax(const void* x, const void* w, int64_t* tokens, int64_t M, int64_t V, int64_t K, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+int ql_lmhead_argmax(const void* x, const void* w, int64_t* tokens, float* max_out, int64_t M, int64_t V, int64_t K,
+                     void* workspace, size_t workspace_bytes, void* stream) {
     const char* fn = "ql_lmhead_argmax";
     if (int rc = head_common(fn, x, w, M, V, K)) return rc;
     if (M > 0 && !tokens) { set_error("%s: bad argument", fn); return QL_EINVAL; }
@@ -553,7 +555,7 @@ int ql_lmhead_argmax(const void* x, const void* w, int64_t* tokens, int64_t M, i
     p.amax = (int2*)workspace;
     if (int rc = run(pick_head(pl.mt, pl.wn, pl.wk, pl.cp, true), p, pl, nullptr, 0, as_stream(stream), fn)) return rc;
     hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)M), dim3(256), 0, as_stream(stream), (const int2*)workspace,
-                       (int)pl.grid.x, tokens);
+                       (int)pl.grid.x, tokens, max_out);
     QL_CHECK_LAUNCH(fn);
     return QL_OK;
 }

@@ -56,7 +56,7 @@ SIGNATURES = {
     "ql_argmax_rows": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_lmhead_logits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ql_lmhead_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
-    "ql_lmhead_argmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "ql_lmhead_argmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
     "ql_attn_prefill": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                                  _c_int, _c_vp]),
     "ql_paged_attn_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),

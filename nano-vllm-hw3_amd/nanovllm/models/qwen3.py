@@ -85,6 +85,26 @@ class VocabParallelEmbedding(nn.Module):
         return y
 
 
+def combine_shard_maxima(vals, toks):
+    """vals f32 [tp, M], toks int64 [tp, M]: per-rank maxima over contiguous ascending vocabulary shards and their
+    (global) tokens -> the tokens of the global maxima; among equal maxima the lowest rank, i.e. the smallest
+    token, wins (argmax returns the first maximal index), and a row whose shards all report -inf gets rank 0's."""
+    r = vals.t().argmax(dim=1, keepdim=True)
+    return toks.t().gather(1, r)[:, 0]
+
+
+def _gather_rows(t, world):
+    """[M] from every rank -> [world, M] on every rank (gloo, the test transport, moves host memory)."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        host = t.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        return torch.stack(parts).to(t.device)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
 class ParallelLMHead(VocabParallelEmbedding):
     """bf16 (unquantized, as in the reference) vocab-parallel output projection; with TP the shards'
     logits are all-gathered so every rank can take the same argmax."""
@@ -94,15 +114,26 @@ class ParallelLMHead(VocabParallelEmbedding):
         self.quantized = None     # a per-row W8A16 QLinear over this rank's vocabulary shard (opt-in: quantize_lm_head)
 
     def fused_sampler(self, x):
-        """True when greedy_tokens(x) can run: bf16 table on this GPU, no vocabulary sharding, K a multiple of 32."""
-        return (FUSE_HEAD_ARGMAX and self.quantized is None and self.tp_size == 1 and x.is_cuda and
+        """True when greedy_tokens(x) can run: bf16 table (or this rank's shard of it) on this GPU, K a multiple of 32."""
+        return (FUSE_HEAD_ARGMAX and self.quantized is None and x.is_cuda and
                 x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and x.shape[-1] % 32 == 0)
 
     def greedy_tokens(self, x, out=None):
         """argmax(forward(x), -1) without the logits reaching memory: the sampler (layers/sampler.py:10-12) runs in
-        the projection's epilogue; bit-identical to ops.argmax_rows(ops.lm_head_logits(x, weight))."""
+        the projection's epilogue; bit-identical to ops.argmax_rows(ops.lm_head_logits(x, weight)).  Vocabulary-
+        parallel ranks take the maximum over their shard and exchange {winning logit, token} pairs (8 bytes per row
+        and rank) where the reference gathers the shards' logits (embed_head.py:62-65)."""
         from nanovllm import ops
-        return ops.lm_head_argmax(x, self.weight, out=out)
+        if self.tp_size == 1:
+            return ops.lm_head_argmax(x, self.weight, out=out)
+        tok, val = ops.lm_head_argmax(x, self.weight, return_max=True)
+        tok = tok + self.start
+        vals, toks = _gather_rows(val, self.tp_size), _gather_rows(tok, self.tp_size)
+        best = combine_shard_maxima(vals, toks)
+        if out is None:
+            return best
+        out.copy_(best)
+        return out
 
     def forward(self, x):
         if self.quantized is not None:

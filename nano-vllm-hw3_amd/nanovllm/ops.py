@@ -161,9 +161,10 @@ def reserve_head_workspace(max_rows, vocab, device=None):
     Q.head_workspace.reserve(device or "cuda", Q.load().ql_lmhead_workspace_bytes(max_rows, vocab))
 
 
-def lm_head_argmax(x, weight, out=None):
+def lm_head_argmax(x, weight, out=None, return_max=False):
     """Greedy tokens int64 [M] = argmax_rows(lm_head_logits(x, weight)) bit for bit, the sampler running in the
-    projection's epilogue: the logits are never written (embed_head.py:61 + layers/sampler.py:10-12)."""
+    projection's epilogue: the logits are never written (embed_head.py:61 + layers/sampler.py:10-12).
+    ``return_max``: also the winning logits as f32 [M] (-inf for a row without a finite maximum)."""
     Q.require_cuda(x, BF16, "x")
     Q.require_cuda(weight, BF16, "weight")
     M, K = x.shape
@@ -174,9 +175,10 @@ def lm_head_argmax(x, weight, out=None):
     assert out.dtype == torch.int64 and out.numel() == M and out.is_contiguous()
     lib = Q.load()
     ws, nbytes = Q.head_workspace.get(x.device, lib.ql_lmhead_workspace_bytes(M, V))
-    Q.check(lib.ql_lmhead_argmax(x.data_ptr(), weight.data_ptr(), out.data_ptr(), M, V, K, ws, nbytes,
-                                 Q.stream_ptr(x.device)))
-    return out
+    mx = torch.empty((M,), dtype=torch.float32, device=x.device) if return_max else None
+    Q.check(lib.ql_lmhead_argmax(x.data_ptr(), weight.data_ptr(), out.data_ptr(), mx.data_ptr() if return_max else None,
+                                 M, V, K, ws, nbytes, Q.stream_ptr(x.device)))
+    return (out, mx) if return_max else out
 
 
 def argmax_rows(logits):

@@ -525,6 +525,18 @@ def _tp_worker(rank, world, port, model_dir, out_path):
             set_context(AttnContext(is_prefill=True, cu_seqlens=[0, ids.numel()], slot_mapping=None))
             h = llm.model_runner.model(ids, torch.arange(ids.numel(), device="cuda")).float().cpu()
         res[name] = dict(tokens=[o["token_ids"] for o in out], hidden=h)
+        # the vocabulary-parallel sampler: per-shard maxima exchanged as {logit, token} pairs must give exactly the
+        # tokens of the unsharded table (same rows on both ranks, the table re-assembled from the shards)
+        import torch.distributed as dist
+        from nanovllm import ops
+        head = llm.model_runner.model.lm_head
+        xg = torch.randn(37, head.weight.shape[1], generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
+        shard = head.weight.data.cpu()
+        parts = [torch.empty_like(shard) for _ in range(world)]
+        dist.all_gather(parts, shard)
+        with torch.inference_mode():
+            assert head.fused_sampler(xg)
+            res[name]["head_equal"] = bool(torch.equal(head.greedy_tokens(xg), ops.lm_head_argmax(xg, torch.cat(parts).cuda())))
         print(f"[tp worker {rank}] {name} done", flush=True)
     if rank == 0:
         torch.save(res, out_path)
@@ -565,6 +577,7 @@ def test_tensor_parallel_engine_two_ranks_one_gpu(tiny_dir, tmp_path):
         rel = (h1 - tp2[name]["hidden"]).abs().max() / h1.abs().max()
         assert rel < tol, (name, float(rel))
         assert all(len(t) == 6 for t in tp2[name]["tokens"])
+        assert tp2[name]["head_equal"], "vocabulary-parallel fused sampler differs from the unsharded one"
 
 
 @pytest.mark.parametrize("quant", [dict(quant_type="per_row_weight_only", linear_dtype=torch.int8),

@@ -101,12 +101,42 @@ def test_every_head_tile_and_exact_ties(tile):
     assert same >= len(rows) * 3 // 4
 
 
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_vocabulary_shards_combine_to_the_unsharded_tokens(shards):
+    """What tensor-parallel ranks do, in one process: every shard's {winning logit, token} pair, combined by
+    combine_shard_maxima, equals the sampler over the whole table - including maxima attained in two shards
+    (the smaller token wins) and rows without a finite maximum."""
+    from nanovllm.models.qwen3 import combine_shard_maxima
+    ops, _ = _ops()
+    M, V, K = 45, 1024 * shards, 128
+    x, w = _rand(M, V, K, seed=shards)
+    win = (37 * torch.arange(M)) % V
+    x = (w[win.cuda()].float() * 40).to(torch.bfloat16)
+    w = w.clone()
+    w[((win + V // 2 + 3) % V).cuda()] = w[win.cuda()]          # the same row again, in another shard
+    x[5] = float("nan")
+    x[6] = 0
+    per = V // shards
+    vals, toks = [], []
+    for r in range(shards):
+        t, v = ops.lm_head_argmax(x, w[r * per:(r + 1) * per].contiguous(), return_max=True)
+        vals.append(v)
+        toks.append(t + r * per)
+    got = combine_shard_maxima(torch.stack(vals), torch.stack(toks))
+    want, vmax = ops.lm_head_argmax(x, w, return_max=True)
+    assert torch.equal(got, want)
+    lf = ops.lm_head_logits(x, w).float()
+    assert torch.equal(vmax[7:], lf.max(-1).values[7:])
+    assert vmax[5].item() == float("-inf") and want[5].item() == 0 and want[6].item() == 0
+    assert sum(int((lf[m] == lf[m].max()).sum() >= 2) for m in range(7, M)) >= (M - 7) * 3 // 4
+
+
 def test_rejections():
     ops, Q = _ops()
     lib = Q.load()
     x, w = _rand(4, 256, 64, seed=1)
     out = torch.empty(4, dtype=torch.int64, device="cuda")
-    assert lib.ql_lmhead_argmax(x.data_ptr(), w.data_ptr(), out.data_ptr(), 4, 256, 64, None, 0, None) == -3
+    assert lib.ql_lmhead_argmax(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, 4, 256, 64, None, 0, None) == -3
     assert b"workspace" in lib.ql_last_error()
     assert lib.ql_lmhead_logits(x.data_ptr(), w.data_ptr(), out.data_ptr(), 4, 256, 48, None) == -2
     assert lib.ql_lmhead_workspace_bytes(256, 151936) == 256 * 1187 * 8
