@@ -141,6 +141,18 @@ int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x_bf16, const vo
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
                       const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* per_row_matmul (nanovllm/utils/quantization.py:310-346) with its per_row_quant(x) (:323) inside the GEMM: x is the
+ * bf16 activation matrix, rowmax_part f32 [M, nparts] holds partial |max| values of every row over ANY split of its
+ * K columns (what the workgroups of the producing kernel each see: ql_gemm_w8a8_silu and the attention kernels can
+ * emit them; ql_row_absmax_parts computes them from x).  The kernel takes their maximum, clamps it at 1e-8 and
+ * quantizes the activations while it stages them, with exactly the arithmetic of ql_quant_per_row; the result is
+ * bit-identical to ql_quant_per_row followed by ql_gemm_w8a8.  Workspace as for ql_gemm_w8a8.
+ * ql_row_absmax_parts: out f32 [T, parts], out[t][i] = max |x[t, i*H/parts : (i+1)*H/parts]|; H % (8 * parts) == 0. */
+int ql_row_absmax_parts(const void* x_bf16, int64_t T, int64_t H, int parts, float* out, void* stream);
+int ql_gemm_w8a8_dynq(int dtype, const void* x_bf16, const float* rowmax_part, int nparts, const void* qw,
+                      const float* sw, const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight-only GEMM whose split-K reduction is left to the NEXT launch.  For the projections that feed a residual
  * add + RMSNorm (o_proj, down_proj: Qwen3DecoderLayer.forward, nanovllm/models/qwen3.py:153-162) the K dimension is
  * cut into ql_gemm_partial_slices(M, N, K, granularity) slices, slice s stores its UNSCALED f32 partial sums at

@@ -303,12 +303,16 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
 
+// rowmax_part != null: qx is the bf16 activation matrix and sx is unused (the kernel quantizes while staging)
 static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const float* sx, const void* qw,
                      const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, void* workspace,
-                     size_t workspace_bytes, void* stream, const RopeArgs* rope = nullptr) {
+                     size_t workspace_bytes, void* stream, const RopeArgs* rope = nullptr,
+                     const float* rowmax_part = nullptr, int nparts = 0) {
     const bool tiled = (dtype & QL_TILED) != 0;
     dtype &= ~QL_TILED;
-    if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || !sx || (!y && !rope))) || !qw || !sw) {
+    const bool dynq = rowmax_part != nullptr;
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || (!sx && !dynq) || (!y && !rope))) || !qw || !sw ||
+        (dynq && (nparts <= 0 || silu || rope))) {
         set_error("%s: bad argument (dtype=%d)", fn, dtype);
         return QL_EINVAL;
     }
@@ -325,8 +329,11 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     p.silu = silu ? 1 : 0;
     p.wtiled = tiled ? 1 : 0;
     if (rope) { p.rope_on = 1; p.rope = *rope; }
+    p.rowmax_part = rowmax_part; p.nparts = nparts;
     const Plan pl = make_plan(M, N, K, false, silu, rope != nullptr);
-    kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr);
+    kern_t k;
+    if (dynq) k = dtype == QL_INT8 ? pick_i8_i8_dynq(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8_dynq(pl.mt, pl.wn, pl.wk, pl.cp);
+    else k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
 
@@ -450,6 +457,14 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
                       void* y, int64_t M, int64_t N, int64_t K, void* stream) {
     return gemm_w8a8("ql_gemm_w8a8_silu", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream);
+}
+
+int ql_gemm_w8a8_dynq(int dtype, const void* x, const float* rowmax_part, int nparts, const void* qw, const float* sw,
+                      const void* bias, void* y, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (!rowmax_part) { set_error("ql_gemm_w8a8_dynq: bad argument"); return QL_EINVAL; }
+    return gemm_w8a8("ql_gemm_w8a8_dynq", false, dtype, x, nullptr, qw, sw, bias, y, M, N, K, workspace, workspace_bytes,
+                     stream, nullptr, rowmax_part, nparts);
 }
 
 // ---- output projection: bf16 activations x the bf16 embedding table, logits or the greedy sampler's tokens ----------

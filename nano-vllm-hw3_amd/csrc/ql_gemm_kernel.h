@@ -59,6 +59,8 @@ struct GemmParams {
                                  // or -R: a 1-D grid in which the R row tiles of a column tile are 8 workgroup ids apart
     int ntile_n;                 // column tiles (the grid's x extent unless swz_gn < 0)
     int wtiled;                  // 1: w is stored as [N/32 strips][K/32 steps][64 lanes][16 bytes] (see ql_tile_weight)
+    const float* rowmax_part;    // DYNQ kernels (W8A8 with the activation quantization in the staging): x is bf16 [M,K],
+    int nparts;                  // rowmax_part [M][nparts] holds partial |max| of every row (any split of its columns)
     int2* amax;                  // AMAX kernels (output projection with the greedy sampler in the epilogue): y is not
                                  // stored; [M][gridDim.x] pairs {f32 bits of the row's maximum over the tile's columns as
                                  // the bf16 the plain kernel would store, its smallest column}, reduced by argmax_finish
@@ -149,12 +151,14 @@ struct Cfg {
 };
 
 template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP, bool ROPE = false, bool W16 = false,
-          bool AMAX = false>
+          bool AMAX = false, bool DYNQ = false>
 __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p) {
     static_assert(!ROPE || WN == 4 || WN == 8, "the qkv epilogue needs whole 128-column heads per workgroup");
     static_assert(!W16 || (ACT == ACT_BF16 && !GROUP && !ROPE && !FP8W), "16-bit weights: plain bf16 x bf16");
     static_assert(!AMAX || (W16 && WK == 1 && WN >= 4), "the sampler epilogue is built for the output projection's tiles");
+    static_assert(!DYNQ || (ACT != ACT_BF16 && !ROPE && !W16 && !GROUP), "dynamic activation quantization: the W8A8 kernels");
     using wreg_t = typename std::conditional<W16, W2, i32x4>::type;
+    using xreg_t = typename std::conditional<DYNQ, W2, i32x4>::type;   // one staged piece: 16 activations as they lie in memory
     using C = Cfg<ACT, MT, WN, WK, CP, DB>;
     constexpr bool INT = (ACT == ACT_I8);
     constexpr int RB = C::RB;
@@ -165,7 +169,9 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     using raw_t = typename std::conditional<INT, int, float>::type;
     using TrueT = std::integral_constant<bool, true>;
     using FalseT = std::integral_constant<bool, false>;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[(ROPE || AMAX) ? C::LDS_ROPE : C::LDS];   // base must be a multiple of 32 (address ^ 16 below)
+    constexpr int LDS_MAIN = (ROPE || AMAX) ? C::LDS_ROPE : C::LDS;
+    constexpr int DQ_OFF = (LDS_MAIN + 15) & ~15;                // DYNQ: per-row {QMAX / max, max / QMAX} behind everything else
+    __shared__ __attribute__((aligned(128))) unsigned char smem[DYNQ ? DQ_OFF + 8 * C::BM : LDS_MAIN];   // base must be a multiple of 32 (address ^ 16 below)
 
     // The kernel is VALU-issue-bound at decode sizes, so everything that is uniform per wave is kept
     // in scalar registers (the wave index is made provably uniform) and every per-lane address is
@@ -224,7 +230,9 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     static_assert(C::NT >= C::CPR, "a row's pieces must not outnumber the threads");
     const int st_ci = tid % C::CPR;
     const int st_row0 = tid / C::CPR;
-    const unsigned xoff0 = ((unsigned)(m0 + st_row0) * (unsigned)p.K) * C::AB + (unsigned)st_ci * 16u;
+    constexpr unsigned XB = DYNQ ? 2u : (unsigned)C::AB;           // bytes per activation element in memory
+    constexpr unsigned XPB = 16u * XB / C::AB;                    // bytes of one staged piece in memory (16 or 32)
+    const unsigned xoff0 = ((unsigned)(m0 + st_row0) * (unsigned)p.K) * XB + (unsigned)st_ci * XPB;
     const int st_k = st_ci * (16 / C::AB);                        // k of this thread's piece inside a chunk
 
     // A-fragment reads: row 32*i + l31; the XOR swizzle only involves lane-constant bits
@@ -265,7 +273,35 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // lead, while two LDS buffers still suffice.
     constexpr bool DEEP = DB && WN == 8 && ACT == ACT_BF16 && !W16;
     wreg_t wcur[D], wnext[(DB && WN != 8) ? CP : 1], wcur2[DEEP ? CP : 1];
-    i32x4 sreg[C::NP], sreg2[DEEP ? C::NP : 1];
+    xreg_t sreg[C::NP], sreg2[DEEP ? C::NP : 1];
+    auto xload = [&](const unsigned char* ptr) -> xreg_t {
+        if constexpr (DYNQ) return W2{gload16(ptr), gload16(ptr + 16)};
+        else return gload16(ptr);
+    };
+    auto xzero = [&]() -> xreg_t {
+        if constexpr (DYNQ) return W2{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+        else return i32x4{0, 0, 0, 0};
+    };
+    // DYNQ: the row maxima come in as partial maxima over any split of the row's columns (what the producing
+    // kernels' workgroups each see); their maximum gives exactly the scale pair of ql_quant_per_row
+    if constexpr (DYNQ) {
+        float* dq = (float*)(smem + DQ_OFF);
+        constexpr int TPR = (C::NT >= C::BM) ? C::NT / C::BM : 1;  // threads per row (a power of two, at most 16)
+        static_assert(C::NT >= C::BM && (TPR & (TPR - 1)) == 0 && TPR <= 64, "row maxima: whole lane groups");
+        constexpr float QMAX = (ACT == ACT_I8) ? 127.f : 448.f;
+        const int r = tid / TPR, part0 = tid % TPR;
+        float mx = 0.f;
+        if (m0 + r < p.M)
+            for (int i = part0; i < p.nparts; i += TPR) mx = fmaxf(mx, p.rowmax_part[(size_t)(m0 + r) * p.nparts + i]);
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (part0 == 0) {
+            const float rm = fmaxf(mx, 1e-8f);
+            dq[r] = QMAX / rm;
+            dq[C::BM + r] = rm / QMAX;
+        }
+        __syncthreads();
+    }
 
     // 16 weight bytes of step c of the chunk at kc (uniform base pointer + 32-bit lane offset)
     auto load_w_at = [&](int kb) -> wreg_t {
@@ -278,14 +314,14 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         if constexpr (W16) return W2{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
         else return i32x4{0, 0, 0, 0};
     };
-    auto load_x_to = [&](auto chk, int kc, i32x4* sreg) {
+    auto load_x_to = [&](auto chk, int kc, xreg_t* sreg) {
         if (fullM) {
             const bool ok = !decltype(chk)::value || (kc + st_k < kend);
-            const unsigned off = ok ? xoff0 : (unsigned)(m0 * p.K) * C::AB;      // any valid address when past the slice
-            const unsigned char* xs = p.x + (size_t)kc * C::AB;
+            const unsigned off = ok ? xoff0 : (unsigned)(m0 * p.K) * XB;         // any valid address when past the slice
+            const unsigned char* xs = p.x + (size_t)kc * XB;
 #pragma unroll
             for (int j = 0; j < C::NP; ++j)
-                sreg[j] = gload16(xs + (size_t)j * RS * p.K * C::AB + off);
+                sreg[j] = xload(xs + (size_t)j * RS * p.K * XB + off);
         } else {
             // last row block: rows past M are not fetched (zeros: their outputs are never stored).  All lanes of a
             // wave hold pieces of the same row whenever a row has at least 64 pieces, so the branch is uniform.
@@ -293,15 +329,34 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
             for (int j = 0; j < C::NP; ++j) {
                 const int row = m0 + st_row0 + j * RS;
                 const int k = (kc + st_k < kend) ? kc + st_k : k0;
-                if (row < p.M) sreg[j] = gload16(p.x + ((size_t)row * p.K + k) * C::AB);
-                else sreg[j] = i32x4{0, 0, 0, 0};
+                if (row < p.M) sreg[j] = xload(p.x + ((size_t)row * p.K + k) * XB);
+                else sreg[j] = xzero();
             }
         }
     };
-    auto store_x_from = [&](int buf, const i32x4* sreg) {
+    auto store_x_from = [&](int buf, const xreg_t* sreg) {
 #pragma unroll
-        for (int j = 0; j < C::NP; ++j)
-            *(i32x4*)(smem + buf * C::XBYTES + lds_off<RB>(st_row0 + j * RS, st_ci)) = sreg[j];
+        for (int j = 0; j < C::NP; ++j) {
+            i32x4 piece;
+            if constexpr (DYNQ) {
+                // the arithmetic of quant_per_row_kernel: y = x * (QMAX / max), round half away (int8) or e4m3 RTNE
+                const float inv = ((const float*)(smem + DQ_OFF))[st_row0 + j * RS];
+                const u16x8 lo = __builtin_bit_cast(u16x8, sreg[j].a), hi = __builtin_bit_cast(u16x8, sreg[j].b);
+                unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float y = bf16_bits_to_f32(e < 8 ? lo[e] : hi[e - 8]) * inv;
+                    unsigned b;
+                    if (ACT == ACT_I8) b = (unsigned)(unsigned char)(signed char)(int)roundf(y);
+                    else b = f32_to_e4m3fn(y);
+                    o[e >> 2] |= b << (8 * (e & 3));
+                }
+                piece = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+            } else {
+                piece = sreg[j];
+            }
+            *(i32x4*)(smem + buf * C::XBYTES + lds_off<RB>(st_row0 + j * RS, st_ci)) = piece;
+        }
     };
     auto load_x = [&](auto chk, int kc) { load_x_to(chk, kc, sreg); };
     auto store_x = [&](int buf) { store_x_from(buf, sreg); };
@@ -597,7 +652,8 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
         // element (fragment i, register r) of this lane as the bf16 the plain GEMM stores
         auto outv = [&](int i, int r, int rowc) -> bf16_t {
             float v = (float)acc[i][r];
-            if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[min(m0 + rowc + 4 * lh, p.M - 1)]);
+            if constexpr (DYNQ) v = __fmul_rn(v, ((const float*)(smem + DQ_OFF))[C::BM + rowc + 4 * lh]);
+            else if (ACT != ACT_BF16) v = __fmul_rn(v, p.sx[min(m0 + rowc + 4 * lh, p.M - 1)]);
             v = __fmul_rn(v, sw);
             if (has_bias) {
                 if (p.bias_after_round) v = __fadd_rn((float)(bf16_t)v, bias);
@@ -798,6 +854,18 @@ kern_t pick_kernel_impl(int mt, int wn, int wk, int cp, bool rope) {
     return nullptr;
 }
 
+// the W8A8 kernels with the activation quantization in their staging (x arrives as bf16 + partial row maxima)
+template <int ACT, bool FP8W>
+kern_t pick_dynq_impl(int mt, int wn, int wk, int cp) {
+#define QL_PICK(MT_, WN_, WK_, CP_, DB_) \
+    if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) \
+        return (kern_t)qgemm_kernel<ACT, FP8W, MT_, WN_, WK_, CP_, DB_, false, false, false, false, true>;
+    QL_TILE_LIST(QL_PICK)
+    QL_TILE_LIST_TALL(QL_PICK)
+#undef QL_PICK
+    return nullptr;
+}
+
 // host side, defined in ql_gemm.hip (see there)
 int w8a16_dispatch(const char* fn, int wdtype, int granularity, const void* x, const void* qw, const float* sw,
                    const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace,
@@ -811,5 +879,7 @@ kern_t pick_bf16_fp8_group(int, int, int, int, bool rope = false);
 kern_t pick_i8_i8(int, int, int, int, bool rope = false);
 kern_t pick_fp8_fp8(int, int, int, int, bool rope = false);
 kern_t pick_head(int, int, int, int, bool amax);
+kern_t pick_i8_i8_dynq(int, int, int, int);
+kern_t pick_fp8_fp8_dynq(int, int, int, int);
 
 }  // namespace ql

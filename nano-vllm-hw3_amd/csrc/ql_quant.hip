@@ -66,6 +66,21 @@ __global__ __launch_bounds__(256) void quant_per_row_kernel(const unsigned short
     }
 }
 
+// ---- partial row maxima: out[row][i] = max |x[row, i*H/parts : (i+1)*H/parts]| (one wave per part) ----
+__global__ __launch_bounds__(256) void row_absmax_parts_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
+                                                               int64_t H, int parts) {
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t per = H / parts;
+    for (int i = threadIdx.x >> 6; i < parts; i += 4) {
+        const unsigned short* xp = x + row * H + (int64_t)i * per;
+        float m = 0.f;
+        for (int64_t c = lane * 8; c < per; c += 64 * 8) m = fmaxf(m, absmax8(*(const u16x8*)(xp + c)));
+        m = wave_max(m);
+        if (lane == 0) out[row * parts + i] = m;
+    }
+}
+
 // ---- per-group: g/8 adjacent lanes share a group ------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void quant_per_group_kernel(const unsigned short* __restrict__ x,
@@ -272,6 +287,20 @@ int ql_quant_per_row(int dtype, const void* x, int64_t T, int64_t H, void* q, fl
         hipLaunchKernelGGL(quant_per_row_kernel<QL_FP8>, grid, block, 0, as_stream(stream),
                            (const unsigned short*)x, (unsigned char*)q, scale, H);
     QL_CHECK_LAUNCH("ql_quant_per_row");
+    return QL_OK;
+}
+
+int ql_row_absmax_parts(const void* x, int64_t T, int64_t H, int parts, float* out, void* stream) {
+    if (T < 0 || H <= 0 || parts <= 0 || (T > 0 && (!x || !out))) { set_error("ql_row_absmax_parts: bad argument"); return QL_EINVAL; }
+    if (H % ((int64_t)parts * 8)) {
+        set_error("ql_row_absmax_parts: H=%lld must be a multiple of 8 * parts (parts=%d)", (long long)H, parts);
+        return QL_ESHAPE;
+    }
+    if (T == 0) return QL_OK;
+    if (T > 0x7FFFFFFF) { set_error("ql_row_absmax_parts: T too large"); return QL_ESHAPE; }
+    hipLaunchKernelGGL(row_absmax_parts_kernel, dim3((unsigned)T), dim3(256), 0, as_stream(stream), (const unsigned short*)x,
+                       out, H, parts);
+    QL_CHECK_LAUNCH("ql_row_absmax_parts");
     return QL_OK;
 }
 

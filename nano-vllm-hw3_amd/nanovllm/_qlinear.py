@@ -54,6 +54,9 @@ SIGNATURES = {
     "ql_qknorm_rope_store": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),
     "ql_argmax_rows": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    "ql_row_absmax_parts": (_c_int, [_c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp]),
+    "ql_gemm_w8a8_dynq": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
+                                   _c_sz, _c_vp]),
     "ql_lmhead_logits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ql_lmhead_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ql_lmhead_argmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),

@@ -220,6 +220,44 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False, out=None)
     return y if y_shape is None else y.view(y_shape)
 
 
+def row_absmax_parts(x, parts):
+    """f32 [M, parts]: |max| of every row of bf16 x [M, K] over ``parts`` equal column ranges."""
+    Q.require_cuda(x, torch.bfloat16, "x")
+    M, K = x.shape
+    out = torch.empty((M, parts), dtype=torch.float32, device=x.device)
+    Q.check(Q.load().ql_row_absmax_parts(x.data_ptr(), M, K, parts, out.data_ptr(), Q.stream_ptr(x.device)))
+    return out
+
+
+@torch.no_grad()
+def w8a8_dynq_matmul(x, rowmax_part, qw, sw, bias, dtype, out=None):
+    """per_row_matmul (quantization.py:310-346) with its activation quantization (:323) inside the GEMM: ``x`` is
+    bf16, ``rowmax_part`` f32 [M, parts] holds partial |max| values of every row of x over any split of its columns
+    (emitted by the kernel that produced x).  Bit-identical to per_row_quant(x) + w8a8_matmul."""
+    assert dtype in _DTYPES
+    x2, y_shape = _flatten(x, qw.size(0))
+    Q.require_cuda(x2, torch.bfloat16, "x")
+    Q.require_cuda(rowmax_part, torch.float32, "rowmax_part")
+    Q.require_cuda(qw, dtype, "qw")
+    Q.require_cuda(sw, torch.float32, "sw")
+    if bias is not None:
+        Q.require_cuda(bias, torch.bfloat16, "bias")
+    M, K = x2.shape
+    N = qw.shape[0]
+    assert qw.shape[1] == K and rowmax_part.dim() == 2 and rowmax_part.shape[0] == M
+    if out is not None:
+        assert out.shape == (M, N)
+        y = Q.require_cuda(out, torch.bfloat16, "out")
+    else:
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    lib = Q.load()
+    ws_ptr, ws_len = Q.workspace.get(x2.device, lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW))
+    Q.check(lib.ql_gemm_w8a8_dynq(_wcode(qw, dtype), x2.data_ptr(), rowmax_part.data_ptr(), rowmax_part.shape[1],
+                                  qw.data_ptr(), sw.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                  y.data_ptr(), M, N, K, ws_ptr, ws_len, Q.stream_ptr(x2.device)))
+    return y if out is not None else y.view(y_shape)
+
+
 @torch.no_grad()
 def per_row_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
     """Dynamic per-token activation quant + W8A8 GEMM (quantization.py:310-346)."""

@@ -779,3 +779,52 @@ def test_one_round_tile_rule_all_variants(NQ, dt):
     from nanovllm import ops
     fused = NQ.per_row_weight_only_matmul(x, NQ.tile_weight(qi), si, None, tdt, silu=True)
     assert torch.equal(fused, ops.silu_mul(y))
+
+
+# ---- W8A8 with the activation quantization inside the GEMM (partial row maxima in, no quantized copy of x) ----
+@pytest.mark.parametrize("dt", ["int8", "fp8"])
+@pytest.mark.parametrize("M,N,K,parts", [(1, 64, 64, 1), (7, 130, 128, 2), (33, 1024, 2048, 8), (130, 1024, 3072, 96),
+                                         (256, 4096, 1024, 4), (300, 192, 96, 3), (2048, 1024, 2048, 16)])
+def test_w8a8_dynamic_quant_in_gemm_bit_identical(NQ, dt, M, N, K, parts):
+    """ql_gemm_w8a8_dynq(x, partial row maxima) == ql_quant_per_row(x) + ql_gemm_w8a8, bit for bit, for partial
+    maxima over any split of the columns (the helper kernel's equal ranges, and an uneven split with a part that
+    is zero), incl. an all-zero row (the 1e-8 floor) and the tiled weight layout."""
+    tdt = TDT[dt]
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    if M > 2:
+        x[2] = 0
+        x[1] *= 37.0
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    qw, sw = NQ.per_row_quant(w, tdt)
+    want = NQ.per_row_matmul(x, qw, sw, None, tdt)
+    pm = NQ.row_absmax_parts(x, parts)
+    assert torch.equal(pm.max(dim=1).values, x.float().abs().max(dim=1).values)
+    got = NQ.w8a8_dynq_matmul(x, pm, qw, sw, None, tdt)
+    assert torch.equal(got, want)
+    # an uneven split: the first 8 columns, the rest, and a part that saw nothing
+    pm2 = torch.stack([x[:, :8].float().abs().amax(1), x[:, 8:].float().abs().amax(1), torch.zeros(M, device="cuda")], 1)
+    assert torch.equal(NQ.w8a8_dynq_matmul(x, pm2.contiguous(), NQ.tile_weight(qw) if N % 32 == 0 else qw, sw, None, tdt), want)
+
+
+@pytest.mark.parametrize("tile", [(1, 1, 4, 2), (1, 1, 8, 4), (1, 2, 4, 8), (2, 2, 4, 8), (2, 4, 2, 4), (2, 4, 1, 4), (4, 4, 1, 4),
+                                  (4, 8, 1, 4), (8, 4, 1, 4), (1, 4, 2, 16)])
+@pytest.mark.parametrize("split", [1, 3])
+def test_w8a8_dynamic_quant_every_tile(NQ, tile, split):
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    M, N, K = 150, 256, 3072
+    g = torch.Generator(device="cuda").manual_seed(sum(tile) + split)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    for tdt in (torch.int8, torch.float8_e4m3fn):
+        qw, sw = NQ.per_row_quant(w, tdt)
+        pm = NQ.row_absmax_parts(x, 6)
+        Q.workspace.reserve("cuda", 64 << 20)
+        assert lib.ql_gemm_force_config(*tile, split) == 0
+        try:
+            want = NQ.per_row_matmul(x, qw, sw, None, tdt)
+            got = NQ.w8a8_dynq_matmul(x, pm, qw, sw, None, tdt)
+        finally:
+            lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+        assert torch.equal(got, want), (tile, split, tdt)
