@@ -149,6 +149,12 @@ int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw
  * bit-identical to ql_quant_per_row followed by ql_gemm_w8a8.  Workspace as for ql_gemm_w8a8.
  * ql_row_absmax_parts: out f32 [T, parts], out[t][i] = max |x[t, i*H/parts : (i+1)*H/parts]|; H % (8 * parts) == 0. */
 int ql_row_absmax_parts(const void* x_bf16, int64_t T, int64_t H, int parts, float* out, void* stream);
+/* ql_gemm_w8a8_silu that also emits what a ql_gemm_w8a8_dynq consumer of y needs: rowmax_part_out f32 [M, N/64],
+ * the |max| of every row of y over each of its 32-column strips (Qwen3MLP.forward, nanovllm/models/qwen3.py:116-118:
+ * gate_up_proj -> SiluAndMul -> down_proj, whose per_row_quant(x) of quantization.py:323 then needs no launch). */
+int ql_gemm_w8a8_silu_rowmax(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
+                             const void* bias_bf16, void* y_bf16, float* rowmax_part_out, int64_t M, int64_t N, int64_t K,
+                             void* stream);
 int ql_gemm_w8a8_dynq(int dtype, const void* x_bf16, const float* rowmax_part, int nparts, const void* qw,
                       const float* sw, const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K,
                       void* workspace, size_t workspace_bytes, void* stream);
@@ -268,6 +274,13 @@ int ql_paged_attn_decode(const void* q_bf16, const void* k_cache, const void* v_
                          const int* block_tables, const int* context_lens, void* out_bf16, float scale,
                          int64_t B, int Hq, int Hkv, int head_dim, int block_size, int max_blocks,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same, also emitting rowmax_part_out f32 [B, Hkv]: the |max| of every row of out over each kv head's
+ * (Hq/Hkv) x 128 outputs, i.e. what ql_gemm_w8a8_dynq takes as rowmax_part (nparts = Hkv) when a W8A8 o_proj
+ * consumes out (nanovllm/models/qwen3.py:89-90: attn -> o_proj, whose per_row_quant(x) then needs no launch). */
+int ql_paged_attn_decode_rowmax(const void* q_bf16, const void* k_cache, const void* v_cache,
+                                const int* block_tables, const int* context_lens, void* out_bf16,
+                                float* rowmax_part_out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
+                                int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -307,7 +307,7 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
 static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const float* sx, const void* qw,
                      const float* sw, const void* bias, void* y, int64_t M, int64_t N, int64_t K, void* workspace,
                      size_t workspace_bytes, void* stream, const RopeArgs* rope = nullptr,
-                     const float* rowmax_part = nullptr, int nparts = 0) {
+                     const float* rowmax_part = nullptr, int nparts = 0, float* rowmax_out = nullptr) {
     const bool tiled = (dtype & QL_TILED) != 0;
     dtype &= ~QL_TILED;
     const bool dynq = rowmax_part != nullptr;
@@ -330,6 +330,7 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     p.wtiled = tiled ? 1 : 0;
     if (rope) { p.rope_on = 1; p.rope = *rope; }
     p.rowmax_part = rowmax_part; p.nparts = nparts;
+    p.rowmax_out = silu ? rowmax_out : nullptr; p.nparts_out = (int)(N / 64);
     const Plan pl = make_plan(M, N, K, false, silu, rope != nullptr);
     kern_t k;
     if (dynq) k = dtype == QL_INT8 ? pick_i8_i8_dynq(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8_dynq(pl.mt, pl.wn, pl.wk, pl.cp);
@@ -457,6 +458,13 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
                       void* y, int64_t M, int64_t N, int64_t K, void* stream) {
     return gemm_w8a8("ql_gemm_w8a8_silu", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream);
+}
+
+int ql_gemm_w8a8_silu_rowmax(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
+                             void* y, float* rowmax_part_out, int64_t M, int64_t N, int64_t K, void* stream) {
+    if (M > 0 && !rowmax_part_out) { set_error("ql_gemm_w8a8_silu_rowmax: bad argument"); return QL_EINVAL; }
+    return gemm_w8a8("ql_gemm_w8a8_silu_rowmax", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream, nullptr,
+                     nullptr, 0, rowmax_part_out);
 }
 
 int ql_gemm_w8a8_dynq(int dtype, const void* x, const float* rowmax_part, int nparts, const void* qw, const float* sw,

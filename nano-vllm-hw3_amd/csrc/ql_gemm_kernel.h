@@ -59,6 +59,8 @@ struct GemmParams {
                                  // or -R: a 1-D grid in which the R row tiles of a column tile are 8 workgroup ids apart
     int ntile_n;                 // column tiles (the grid's x extent unless swz_gn < 0)
     int wtiled;                  // 1: w is stored as [N/32 strips][K/32 steps][64 lanes][16 bytes] (see ql_tile_weight)
+    float* rowmax_out;           // SiLU epilogue only, may be null: [M][nparts_out] f32, |max| of every output row over each
+    int nparts_out;              // 32-column strip of y (what a DYNQ consumer of y takes as rowmax_part)
     const float* rowmax_part;    // DYNQ kernels (W8A8 with the activation quantization in the staging): x is bf16 [M,K],
     int nparts;                  // rowmax_part [M][nparts] holds partial |max| of every row (any split of its columns)
     int2* amax;                  // AMAX kernels (output projection with the greedy sampler in the epilogue): y is not
@@ -685,18 +687,34 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
                             ex[(i * 16 + r) * 64] = __builtin_bit_cast(unsigned short, outv(i, r, 32 * i + (r & 3) + 8 * (r >> 2)));
                         }
                     __syncthreads();
-                    if (!nvalid) return;
+                    const bool want_max = p.rowmax_out != nullptr;          // (uniform)
+                    if (!nvalid && !want_max) return;
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int rr = 0; rr < RH; ++rr) {
                             const int r = RMINE + rr;
                             const int rowc = 32 * i + (r & 3) + 8 * (r >> 2);
-                            if (!fullM && m0 + rowc + 4 * lh >= p.M) continue;
-                            const float own = (float)outv(i, r, rowc);
-                            const float oth = bf16_bits_to_f32(ex[(i * 16 + r) * 64]);
-                            unsigned short* yrow = p.y + (size_t)(m0 + rowc) * I;
-                            yrow[lane_off] = UP ? silu_mul_bf16(oth, own) : silu_mul_bf16(own, oth);
+                            const bool row_ok = fullM || m0 + rowc + 4 * lh < p.M;   // (uniform per 32-lane half)
+                            if (!row_ok) continue;
+                            unsigned short v = 0;
+                            if (nvalid) {
+                                const float own = (float)outv(i, r, rowc);
+                                const float oth = bf16_bits_to_f32(ex[(i * 16 + r) * 64]);
+                                v = UP ? silu_mul_bf16(oth, own) : silu_mul_bf16(own, oth);
+                                (p.y + (size_t)(m0 + rowc) * I)[lane_off] = v;
+                            }
+                            if (want_max) {
+                                // |v| as bf16 bits orders like the value; a NaN counts as 0 (fmaxf in the quantizer
+                                // drops it too).  Maximum over the 32 columns of this strip, which lie in one half-wave.
+                                int a = v & 0x7FFF;
+                                if (a > 0x7F80) a = 0;
+#pragma unroll
+                                for (int o = 16; o > 0; o >>= 1) a = max(a, __shfl_xor(a, o));
+                                if (l31 == 0)
+                                    p.rowmax_out[(size_t)(m0 + rowc + 4 * lh) * p.nparts_out + ((bx * WN + wn) >> 1)] =
+                                        bf16_bits_to_f32((unsigned short)a);
+                            }
                         }
                 };
                 if (wn & 1) pair(TrueT{});

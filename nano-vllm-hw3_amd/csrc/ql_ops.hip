@@ -217,15 +217,17 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const unsigned short* __restrict__ q, const unsigned short* __restrict__ k_cache,
     const unsigned short* __restrict__ v_cache, const int* __restrict__ block_tables,
     const int* __restrict__ context_lens, unsigned short* __restrict__ out, float scale, int Hq, int Hkv,
-    int block_size, int max_blocks, int max_chunks, float* __restrict__ partial) {
+    int block_size, int max_blocks, int max_chunks, float* __restrict__ partial, float* __restrict__ rowmax_out) {
     __shared__ float st_m[16][G], st_l[16][G];
     __shared__ float st_acc[16][G][128];
     const int b = blockIdx.x, hk = blockIdx.y, sp = blockIdx.z;
     const int ctx = context_lens[b];
     const int nsp = (ctx + kAttnChunk - 1) / kAttnChunk;
     if (ctx == 0) {
-        if (sp == 0)
+        if (sp == 0) {
             for (int o = threadIdx.x; o < G * 128; o += 256) out[((size_t)b * Hq + hk * G) * 128 + o] = 0;
+            if (rowmax_out && threadIdx.x == 0) rowmax_out[(size_t)b * Hkv + hk] = 0.f;
+        }
         return;
     }
     if (sp >= nsp) return;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     __syncthreads();
     const size_t tile = (size_t)b * Hkv + hk;
     float* mypart = partial + ((tile * max_chunks + sp) * G) * 130;
+    float amax = 0.f;                                              // |max| of the bf16 outputs this thread stores
     for (int o = threadIdx.x; o < G * 128; o += 256) {
         const int g = o >> 7, d = o & 127;
         float mm = -1e30f;
@@ -310,11 +313,23 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
             den += wgt * st_l[s][g];
         }
         if (nsp == 1) {
-            out[((size_t)b * Hq + hk * G + g) * 128 + d] = f32_to_bf16_bits(num / den);
+            const unsigned short ob = f32_to_bf16_bits(num / den);
+            out[((size_t)b * Hq + hk * G + g) * 128 + d] = ob;
+            amax = fmaxf(amax, fabsf(bf16_bits_to_f32(ob)));
         } else {
             mypart[g * 130 + 2 + d] = num;
             if (d == 0) { mypart[g * 130] = mm; mypart[g * 130 + 1] = den; }
         }
+    }
+    // what a consumer that quantizes this row on the fly needs: the |max| over this kv head's G x 128 outputs
+    // (single-chunk sequences; the merge launch writes it for the others)
+    if (rowmax_out && nsp == 1) {
+        __syncthreads();                                           // (st_m is free again)
+        amax = wave_max(amax);
+        if (lane == 0) st_m[wave][0] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            rowmax_out[(size_t)b * Hkv + hk] = fmaxf(fmaxf(st_m[0][0], st_m[1][0]), fmaxf(st_m[2][0], st_m[3][0]));
     }
 }
 
@@ -323,11 +338,13 @@ template <int G>
 __global__ __launch_bounds__(256) void paged_attn_combine_kernel(const int* __restrict__ context_lens,
                                                                  const float* __restrict__ partial,
                                                                  unsigned short* __restrict__ out, int Hq, int Hkv,
-                                                                 int max_chunks) {
+                                                                 int max_chunks, float* __restrict__ rowmax_out) {
+    __shared__ float sh[4];
     const int b = blockIdx.x, hk = blockIdx.y;
     const int nsp = (context_lens[b] + kAttnChunk - 1) / kAttnChunk;
     if (nsp <= 1) return;
     const float* parts = partial + (((size_t)b * Hkv + hk) * max_chunks) * G * 130;
+    float amax = 0.f;
     for (int o = threadIdx.x; o < G * 128; o += 256) {
         const int g = o >> 7, d = o & 127;
         float mm = -1e30f;
@@ -339,7 +356,15 @@ __global__ __launch_bounds__(256) void paged_attn_combine_kernel(const int* __re
             num += wgt * ps[2 + d];
             den += wgt * ps[1];
         }
-        out[((size_t)b * Hq + hk * G + g) * 128 + d] = f32_to_bf16_bits(num / den);
+        const unsigned short ob = f32_to_bf16_bits(num / den);
+        out[((size_t)b * Hq + hk * G + g) * 128 + d] = ob;
+        amax = fmaxf(amax, fabsf(bf16_bits_to_f32(ob)));
+    }
+    if (rowmax_out) {
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) rowmax_out[(size_t)b * Hkv + hk] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     }
 }
 
@@ -495,9 +520,10 @@ size_t ql_paged_attn_workspace_bytes(int64_t B, int Hq, int Hkv, int block_size,
     return (size_t)B * Hkv * chunks * (Hq / Hkv) * 130 * 4;
 }
 
-int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
-                         const int* context_lens, void* out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
-                         int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream) {
+static int paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
+                             const int* context_lens, void* out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
+                             int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream,
+                             float* rowmax_out) {
     if (B < 0 || Hq <= 0 || Hkv <= 0 || block_size <= 0 || max_blocks <= 0 ||
         (B > 0 && (!q || !k_cache || !v_cache || !block_tables || !context_lens || !out))) {
         set_error("ql_paged_attn_decode: bad argument");
@@ -520,15 +546,33 @@ int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache
     do {                                                                                                            \
         hipLaunchKernelGGL(paged_attn_decode_kernel<G_>, grid, block, 0, s, (const unsigned short*)q,               \
                            (const unsigned short*)k_cache, (const unsigned short*)v_cache, block_tables, context_lens, \
-                           (unsigned short*)out, scale, Hq, Hkv, block_size, max_blocks, (int)chunks, (float*)workspace); \
+                           (unsigned short*)out, scale, Hq, Hkv, block_size, max_blocks, (int)chunks, (float*)workspace, \
+                           rowmax_out);                                                                             \
         if (chunks > 1)                                                                                             \
             hipLaunchKernelGGL(paged_attn_combine_kernel<G_>, dim3((unsigned)B, (unsigned)Hkv), block, 0, s,        \
-                               context_lens, (const float*)workspace, (unsigned short*)out, Hq, Hkv, (int)chunks);  \
+                               context_lens, (const float*)workspace, (unsigned short*)out, Hq, Hkv, (int)chunks,   \
+                               rowmax_out);                                                                         \
     } while (0)
     if (G == 1) QL_ATT(1); else if (G == 2) QL_ATT(2); else QL_ATT(4);
 #undef QL_ATT
     QL_CHECK_LAUNCH("ql_paged_attn_decode");
     return QL_OK;
+}
+
+int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
+                         const int* context_lens, void* out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
+                         int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream) {
+    return paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, out, scale, B, Hq, Hkv, head_dim, block_size,
+                             max_blocks, workspace, workspace_bytes, stream, nullptr);
+}
+
+int ql_paged_attn_decode_rowmax(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
+                                const int* context_lens, void* out, float* rowmax_part_out, float scale, int64_t B, int Hq,
+                                int Hkv, int head_dim, int block_size, int max_blocks, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (B > 0 && !rowmax_part_out) { set_error("ql_paged_attn_decode_rowmax: bad argument"); return QL_EINVAL; }
+    return paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, out, scale, B, Hq, Hkv, head_dim, block_size,
+                             max_blocks, workspace, workspace_bytes, stream, rowmax_part_out);
 }
 
 }  // extern "C"

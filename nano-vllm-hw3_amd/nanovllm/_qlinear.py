@@ -55,6 +55,7 @@ SIGNATURES = {
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),
     "ql_argmax_rows": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_row_absmax_parts": (_c_int, [_c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp]),
+    "ql_gemm_w8a8_silu_rowmax": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ql_gemm_w8a8_dynq": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
                                    _c_sz, _c_vp]),
     "ql_lmhead_logits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
@@ -65,6 +66,8 @@ SIGNATURES = {
     "ql_paged_attn_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
     "ql_paged_attn_decode": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64, _c_int, _c_int,
                                       _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "ql_paged_attn_decode_rowmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64, _c_int,
+                                             _c_int, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
 }
 
 _lib = None

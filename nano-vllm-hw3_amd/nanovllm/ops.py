@@ -107,9 +107,12 @@ def reserve_attn_workspace(max_batch, num_heads, num_kv_heads, block_size, max_b
     return n
 
 
-def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale):
-    """q [B,Hq,D]; caches [num_blocks, block_size, Hkv, D] -> out [B,Hq,D]."""
+def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale, return_rowmax=False):
+    """q [B,Hq,D]; caches [num_blocks, block_size, Hkv, D] -> out [B,Hq,D].  ``return_rowmax``: also f32 [B, Hkv],
+    the |max| of every output row over each kv head's columns (the partial row maxima a W8A8 o_proj that quantizes
+    its input inside the GEMM asks for)."""
     if not q.is_cuda:
+        assert not return_rowmax
         return cpu_ops.paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale)
     Q.require_cuda(q, BF16, "q")
     B, Hq, D = q.shape
@@ -118,6 +121,13 @@ def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale):
     lib = Q.load()
     max_blocks = block_tables.shape[1]
     ws_ptr, ws_len = Q.attn_workspace.get(q.device, lib.ql_paged_attn_workspace_bytes(B, Hq, Hkv, block_size, max_blocks))
+    if return_rowmax:
+        rowmax = torch.empty((B, Hkv), dtype=torch.float32, device=q.device)
+        Q.check(lib.ql_paged_attn_decode_rowmax(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                                block_tables.data_ptr(), context_lens.data_ptr(), out.data_ptr(),
+                                                rowmax.data_ptr(), scale, B, Hq, Hkv, D, block_size, max_blocks, ws_ptr,
+                                                ws_len, Q.stream_ptr(q.device)))
+        return out, rowmax
     Q.check(lib.ql_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
                                      context_lens.data_ptr(), out.data_ptr(), scale, B, Hq, Hkv, D, block_size,
                                      max_blocks, ws_ptr, ws_len, Q.stream_ptr(q.device)))

@@ -189,8 +189,9 @@ def per_row_weight_only_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
 
 
 @torch.no_grad()
-def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False, out=None):
-    """The dual-scale GEMM on already-quantized activations (quantization.py:54-144, 331-345)."""
+def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False, out=None, return_rowmax=False):
+    """The dual-scale GEMM on already-quantized activations (quantization.py:54-144, 331-345).  ``return_rowmax``
+    (SiLU form only): also f32 [M, N/64], the |max| of every output row over each 32-column strip."""
     assert dtype in _DTYPES
     Q.require_cuda(qx, dtype, "qx")
     Q.require_cuda(qw, dtype, "qw")
@@ -202,8 +203,15 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False, out=None)
     N = qw.shape[0]
     assert qw.shape[1] == K
     lib = Q.load()
+    assert silu or not return_rowmax
     if silu:
         y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=qx.device)
+        if return_rowmax:
+            rowmax = torch.empty((M, N // 64), dtype=torch.float32, device=qx.device)
+            Q.check(lib.ql_gemm_w8a8_silu_rowmax(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(),
+                                                 sw.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 y.data_ptr(), rowmax.data_ptr(), M, N, K, Q.stream_ptr(qx.device)))
+            return (y if y_shape is None else y.view(y_shape)), rowmax
         Q.check(lib.ql_gemm_w8a8_silu(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
                                       Q.stream_ptr(qx.device)))

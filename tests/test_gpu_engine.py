@@ -167,6 +167,13 @@ def test_paged_attn_decode_matches_torch(G):
         s = torch.einsum("hd,lhd->hl", q[b].float(), k) * D ** -0.5
         ref = torch.einsum("hl,lhd->hd", s.softmax(-1), v)
         _close(out[b], ref, rtol=2 ** -6, atol=2e-2)
+    # the variant that also emits partial row maxima (for a W8A8 o_proj that quantizes its input in the GEMM): same
+    # outputs bit for bit; every (sequence, kv head) entry is exactly the |max| of that head group's outputs, for
+    # single-chunk rows (attention launch), multi-chunk rows (merge launch) and padded rows
+    rm0 = torch.full((B, Hkv), -1.0, device="cuda")
+    out2, rm = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5, return_rowmax=True)
+    assert torch.equal(out2, out) and rm.shape == rm0.shape
+    assert torch.equal(rm, out.view(B, Hkv, G * D).float().abs().amax(-1))
 
 
 @pytest.mark.parametrize("G", [1, 2, 4])

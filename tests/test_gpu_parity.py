@@ -828,3 +828,36 @@ def test_w8a8_dynamic_quant_every_tile(NQ, tile, split):
         finally:
             lib.ql_gemm_force_config(0, 0, 0, 0, 0)
         assert torch.equal(got, want), (tile, split, tdt)
+
+
+@pytest.mark.parametrize("dt", ["int8", "fp8"])
+@pytest.mark.parametrize("M,tile", [(5, None), (64, None), (130, None), (256, None), (700, None), (2100, None),
+                                    (70, (1, 2, 4, 8)), (70, (2, 2, 4, 8)), (70, (2, 4, 2, 4)), (70, (2, 4, 2, 16)),
+                                    (70, (1, 4, 2, 16)), (200, (2, 4, 1, 4)), (200, (4, 4, 1, 4)), (200, (4, 8, 1, 4))])
+def test_w8a8_mlp_without_a_quantization_launch(NQ, dt, M, tile):
+    """gate_up (W8A8, SiLU epilogue) -> down (W8A8): the gate/up GEMM also emits the |max| of every output row per
+    32-column strip, and the down GEMM quantizes its input while staging it.  Outputs of both GEMMs are bit-identical
+    to the chain with a separate ql_quant_per_row launch; the emitted maxima are exact."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    tdt = TDT[dt]
+    I, H = 384, 256                                   # intermediate (12 strips), hidden
+    g = torch.Generator(device="cuda").manual_seed(M + (sum(tile) if tile else 0))
+    x = torch.randn(M, H, device="cuda", dtype=torch.bfloat16, generator=g)
+    wgu = (torch.randn(2 * I, H, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    wd = (torch.randn(H, I, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    qgu, sgu = NQ.per_row_quant(wgu, tdt)
+    qgu, sgu = NQ.interleave_gate_up(qgu), NQ.interleave_gate_up(sgu)
+    qd, sd = NQ.per_row_quant(wd, tdt)
+    qx, sx = NQ.per_row_quant(x, tdt)
+    if tile:
+        assert lib.ql_gemm_force_config(*tile, 1) == 0
+    try:
+        y_ref = NQ.w8a8_matmul(qx, sx, qgu, sgu, None, tdt, silu=True)
+        y, rm = NQ.w8a8_matmul(qx, sx, qgu, sgu, None, tdt, silu=True, return_rowmax=True)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+    assert torch.equal(y, y_ref)
+    assert rm.shape == (M, 2 * I // 64)
+    assert torch.equal(rm, y.float().abs().view(M, I // 32, 32).amax(-1))
+    assert torch.equal(NQ.w8a8_dynq_matmul(y, rm, qd, sd, None, tdt), NQ.per_row_matmul(y, qd, sd, None, tdt))
