@@ -157,6 +157,12 @@ class ParallelLMHead(VocabParallelEmbedding):
         return logits
 
 
+def _takes_rowmax(linear):
+    """A W8A8 module that can quantize its bf16 input inside the GEMM from partial row maxima."""
+    from nanovllm.utils import quantization as NQ
+    return NQ.FUSE_ACT_QUANT and isinstance(linear, NQ.QLinear) and not linear.weight_only and linear.qw.shape[1] % 32 == 0
+
+
 class Qwen3Attention(nn.Module):
     def __init__(self, cfg, cos_sin):
         super().__init__()
@@ -199,6 +205,12 @@ class Qwen3Attention(nn.Module):
                 cu_dev = torch.tensor(ctx.cu_seqlens, dtype=torch.int32, device=q.device)
             max_len = ctx.max_seqlen or max(b - a for a, b in zip(ctx.cu_seqlens[:-1], ctx.cu_seqlens[1:]))
             o = ops.attn_prefill(q, k, v, cu_dev, max_len, self.scaling)
+        elif _takes_rowmax(self.o_proj):
+            # a W8A8 o_proj: the attention launches also emit the partial row maxima of their output, and the
+            # projection quantizes its input inside the GEMM (no per_row_quant launch in between)
+            o, rowmax = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens,
+                                              self.scaling, return_rowmax=True)
+            return self.o_proj.forward_with_rowmax(o.view(o.shape[0], -1), rowmax)
         else:
             o = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scaling)
         o = o.view(o.shape[0], -1)
@@ -214,6 +226,11 @@ class Qwen3MLP(nn.Module):
         self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False)
 
     def forward(self, x, quantized=None):
+        if quantized is not None and getattr(self.gate_up_proj, "silu_fused", False) and _takes_rowmax(self.down_proj):
+            # W8A8 MLP: the gate/up GEMM's SiLU epilogue also emits the partial row maxima of its output, and the
+            # down projection quantizes its input inside the GEMM
+            h, rowmax = self.gate_up_proj.forward_quantized(*quantized, return_rowmax=True)
+            return self.down_proj.forward_with_rowmax(h, rowmax)
         h = self.gate_up_proj(x) if quantized is None else self.gate_up_proj.forward_quantized(*quantized)
         if not getattr(self.gate_up_proj, "silu_fused", False):   # else the GEMM epilogue already applied SiLU * mul
             h = ops.silu_mul(h)

@@ -23,6 +23,12 @@ _DTYPES = [torch.float8_e4m3fn, torch.int8]
 # o_proj / down_proj of a weight-only quantized model hand their split-K reduction to the norm launch behind them
 # (NANOVLLM_NO_DEFER_SPLITK=1 keeps the self-contained GEMM, for A/B measurements)
 import os as _os
+# Opt-in (NANOVLLM_DYNQ=1): W8A8 o_proj / down_proj take their input's partial row maxima from the kernel that
+# produced it and quantize inside the GEMM, one launch less each and bit-identical results - but measured SLOWER than
+# the separate ql_quant_per_row launch: every one of the N/32 column-tile workgroups quantizes the activation tile
+# again (int8 o_proj at 128 rows: 8.7 us against 7.3 us for quantize + GEMM; fp8 21.6 against 7.7 with the software
+# e4m3 conversion; whole bench 30.2 k against 31.5 k tok/s for int8, 24.2 k against 30.3 k for fp8).
+FUSE_ACT_QUANT = _os.environ.get("NANOVLLM_DYNQ", "") != ""
 DEFER_SPLITK = _os.environ.get("NANOVLLM_NO_DEFER_SPLITK", "") == ""
 
 
@@ -514,12 +520,26 @@ class QLinear(_QBase):
         RMSNorm launch, ops.add_rmsnorm_quant) and call forward_quantized."""
         return not self.weight_only
 
-    def forward_quantized(self, qx: torch.Tensor, sx: torch.Tensor):
-        """forward() on activations already quantized per row: qx [M, K] in self.dtype, sx [M] f32."""
+    def forward_quantized(self, qx: torch.Tensor, sx: torch.Tensor, return_rowmax: bool = False):
+        """forward() on activations already quantized per row: qx [M, K] in self.dtype, sx [M] f32.
+        ``return_rowmax`` (a gate/up projection with the SiLU epilogue): also the partial row maxima of the output
+        that the next W8A8 linear's forward_with_rowmax consumes."""
         assert not self.weight_only
+        if return_rowmax:
+            assert self.silu_fused
+            return w8a8_matmul(qx, sx, self.qw, self.sw, self._bias_for_rank(), self.dtype, None, True, None, True)
         return self._run(qx, lambda rows, out: w8a8_matmul(
             qx if rows is None else qx[rows], sx if rows is None else sx[rows], self.qw, self.sw,
             self._bias_for_rank(), self.dtype, None, self.silu_fused, out))
+
+    def forward_with_rowmax(self, x: torch.Tensor, rowmax_part: torch.Tensor):
+        """forward() of the W8A8 form on bf16 activations whose partial row maxima the producing kernel emitted
+        (f32 [M, parts], any split of the columns): the activation quantization of per_row_matmul
+        (quantization.py:323) happens inside the GEMM, bit-identical to forward(x) and one launch less."""
+        assert not self.weight_only and not self.silu_fused and x.dim() == 2
+        return self._run(x, lambda rows, out: w8a8_dynq_matmul(
+            x if rows is None else x[rows], rowmax_part if rows is None else rowmax_part[rows], self.qw, self.sw,
+            self._bias_for_rank(), self.dtype, out))
 
 
 class QTensorLinear(_QBase):

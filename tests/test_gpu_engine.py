@@ -302,6 +302,34 @@ def test_engine_quantized_variants(tiny_dir, kw):
     assert rel < 0.1, float(rel)
 
 
+@pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn])
+def test_w8a8_engine_without_activation_quant_launches(tiny_dir, dtype):
+    """W8A8 engine with NANOVLLM_DYNQ: o_proj and down_proj quantize their input inside the GEMM from the partial
+    row maxima that decode attention / the gate-up SiLU epilogue emit.  Same tokens as the default engine, which
+    keeps the separate ql_quant_per_row launches (the kernels are bit-identical), through eager steps and graphs."""
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.utils import quantization as NQ
+    sp = SamplingParams(max_tokens=20, ignore_eos=True)
+    kw = dict(load_format="dummy", max_model_len=512, max_num_seqs=16, quant_type="per_row", linear_dtype=dtype)
+    was = NQ.FUSE_ACT_QUANT                     # (an opt-in: measured slower than the separate launch)
+    calls = []
+    orig = NQ.w8a8_dynq_matmul
+    NQ.w8a8_dynq_matmul = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    NQ.FUSE_ACT_QUANT = True
+    try:
+        out_f = [o["token_ids"] for o in LLM(tiny_dir, enforce_eager=False, **kw).generate(_prompts(6), sp)]
+        out_fe = [o["token_ids"] for o in LLM(tiny_dir, enforce_eager=True, **kw).generate(_prompts(6), sp)]
+        assert calls, "the fused path did not run"
+        NQ.FUSE_ACT_QUANT = False
+        n = len(calls)
+        out_p = [o["token_ids"] for o in LLM(tiny_dir, enforce_eager=True, **kw).generate(_prompts(6), sp)]
+        assert len(calls) == n, "the switch did not turn the fused path off"
+    finally:
+        NQ.w8a8_dynq_matmul = orig
+        NQ.FUSE_ACT_QUANT = was
+    assert out_f == out_p and out_fe == out_p
+
+
 def test_quantized_lm_head_opt_in(tiny_dir):
     """quantize_lm_head=True: the vocabulary projection runs through the per-row W8A16 kernel; logits stay
     within int8 weight-quantization noise of the bf16 head (max error < 2 % of the logit range, the bar the
