@@ -274,6 +274,13 @@ int ql_paged_attn_decode(const void* q_bf16, const void* k_cache, const void* v_
                          const int* block_tables, const int* context_lens, void* out_bf16, float scale,
                          int64_t B, int Hq, int Hkv, int head_dim, int block_size, int max_blocks,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a W8A8 o_proj (nanovllm/models/qwen3.py:89-90: attn -> o_proj): the merge launch also takes over the
+ * per_row_quant(x) that per_row_matmul runs on its input (nanovllm/utils/quantization.py:323).  q_out [B, Hq*128] in
+ * `dtype` and scale_out f32 [B] are bit-identical to ql_quant_per_row(out); out is written as well. */
+int ql_paged_attn_decode_quant(int dtype, const void* q_bf16, const void* k_cache, const void* v_cache,
+                               const int* block_tables, const int* context_lens, void* out_bf16, void* q_out,
+                               float* scale_out, float scale, int64_t B, int Hq, int Hkv, int head_dim, int block_size,
+                               int max_blocks, void* workspace, size_t workspace_bytes, void* stream);
 /* The same, also emitting rowmax_part_out f32 [B, Hkv]: the |max| of every row of out over each kv head's
  * (Hq/Hkv) x 128 outputs, i.e. what ql_gemm_w8a8_dynq takes as rowmax_part (nparts = Hkv) when a W8A8 o_proj
  * consumes out (nanovllm/models/qwen3.py:89-90: attn -> o_proj, whose per_row_quant(x) then needs no launch). */

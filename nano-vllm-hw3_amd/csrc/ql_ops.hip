@@ -368,6 +368,71 @@ __global__ __launch_bounds__(256) void paged_attn_combine_kernel(const int* __re
     }
 }
 
+// The merge launch for a W8A8 o_proj: one workgroup per sequence finishes ALL its heads (single-chunk heads were
+// written by the attention launch, the others are merged here with paged_attn_combine_kernel's arithmetic), takes the
+// row's |max| and writes the row quantized per ql_quant_per_row - the per_row_quant(x) of per_row_matmul
+// (nanovllm/utils/quantization.py:323) without a launch of its own.  Two passes over the row's own bf16 outputs.
+template <int G, int DT>
+__global__ __launch_bounds__(256) void paged_attn_finalize_quant_kernel(const int* __restrict__ context_lens,
+                                                                        const float* __restrict__ partial,
+                                                                        unsigned short* __restrict__ out,
+                                                                        unsigned char* __restrict__ q_out,
+                                                                        float* __restrict__ scale_out, int Hq, int Hkv,
+                                                                        int max_chunks) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    const int nsp = (context_lens[b] + kAttnChunk - 1) / kAttnChunk;
+    const int E = Hq * 128;
+    unsigned short* orow = out + (size_t)b * E;
+    float amax = 0.f;
+    for (int e = threadIdx.x * 8; e < E; e += 256 * 8) {
+        u16x8 o8;
+        if (nsp <= 1) {
+            o8 = *(const u16x8*)(orow + e);
+        } else {
+            const int h = e >> 7, hk = h / G, g = h % G, d0 = e & 127;
+            const float* parts = partial + (((size_t)b * Hkv + hk) * max_chunks) * G * 130;
+            float mm = -1e30f;
+            for (int s = 0; s < nsp; ++s) mm = fmaxf(mm, parts[(s * G + g) * 130]);
+            float num[8], den = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) num[k] = 0.f;
+            for (int s = 0; s < nsp; ++s) {
+                const float* ps = parts + (s * G + g) * 130;
+                const float wgt = __expf(ps[0] - mm);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) num[k] += wgt * ps[2 + d0 + k];
+                den += wgt * ps[1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = f32_to_bf16_bits(num[k] / den);
+            *(u16x8*)(orow + e) = o8;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(bf16_bits_to_f32(o8[k])));
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    constexpr float QMAX = (DT == QL_INT8) ? 127.f : 448.f;
+    const float row_max = fmaxf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), 1e-8f);
+    const float sc_inv = QMAX / row_max;
+    if (threadIdx.x == 0) scale_out[b] = row_max / QMAX;
+    for (int e = threadIdx.x * 8; e < E; e += 256 * 8) {
+        const u16x8 o8 = *(const u16x8*)(orow + e);            // (this thread's own stores, or the attention launch's)
+        unsigned long long o = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float y = bf16_bits_to_f32(o8[k]) * sc_inv;
+            unsigned bq;
+            if (DT == QL_INT8) bq = (unsigned)(unsigned char)(signed char)(int)roundf(y);
+            else bq = f32_to_e4m3fn(y);
+            o |= (unsigned long long)bq << (8 * k);
+        }
+        *(unsigned long long*)(q_out + (size_t)b * E + e) = o;
+    }
+}
+
 // ---- greedy sampling: index of the row maximum of bf16 logits (smallest index among equal maxima) ---------
 // One workgroup per row, 16-byte loads; the reference's sampler takes the argmax of the logits
 // (nanovllm/layers/sampler.py:10-12).  NaNs never win.
@@ -523,7 +588,7 @@ size_t ql_paged_attn_workspace_bytes(int64_t B, int Hq, int Hkv, int block_size,
 static int paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
                              const int* context_lens, void* out, float scale, int64_t B, int Hq, int Hkv, int head_dim,
                              int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream,
-                             float* rowmax_out) {
+                             float* rowmax_out, int qdt = -1, void* q_out = nullptr, float* scale_out = nullptr) {
     if (B < 0 || Hq <= 0 || Hkv <= 0 || block_size <= 0 || max_blocks <= 0 ||
         (B > 0 && (!q || !k_cache || !v_cache || !block_tables || !context_lens || !out))) {
         set_error("ql_paged_attn_decode: bad argument");
@@ -548,7 +613,15 @@ static int paged_attn_decode(const void* q, const void* k_cache, const void* v_c
                            (const unsigned short*)k_cache, (const unsigned short*)v_cache, block_tables, context_lens, \
                            (unsigned short*)out, scale, Hq, Hkv, block_size, max_blocks, (int)chunks, (float*)workspace, \
                            rowmax_out);                                                                             \
-        if (chunks > 1)                                                                                             \
+        if (qdt == QL_INT8)                                                                                         \
+            hipLaunchKernelGGL((paged_attn_finalize_quant_kernel<G_, QL_INT8>), dim3((unsigned)B), block, 0, s,     \
+                               context_lens, (const float*)workspace, (unsigned short*)out, (unsigned char*)q_out,  \
+                               scale_out, Hq, Hkv, (int)chunks);                                                    \
+        else if (qdt == QL_FP8)                                                                                     \
+            hipLaunchKernelGGL((paged_attn_finalize_quant_kernel<G_, QL_FP8>), dim3((unsigned)B), block, 0, s,      \
+                               context_lens, (const float*)workspace, (unsigned short*)out, (unsigned char*)q_out,  \
+                               scale_out, Hq, Hkv, (int)chunks);                                                    \
+        else if (chunks > 1)                                                                                        \
             hipLaunchKernelGGL(paged_attn_combine_kernel<G_>, dim3((unsigned)B, (unsigned)Hkv), block, 0, s,        \
                                context_lens, (const float*)workspace, (unsigned short*)out, Hq, Hkv, (int)chunks,   \
                                rowmax_out);                                                                         \
@@ -564,6 +637,18 @@ int ql_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache
                          int block_size, int max_blocks, void* workspace, size_t workspace_bytes, void* stream) {
     return paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, out, scale, B, Hq, Hkv, head_dim, block_size,
                              max_blocks, workspace, workspace_bytes, stream, nullptr);
+}
+
+int ql_paged_attn_decode_quant(int dtype, const void* q, const void* k_cache, const void* v_cache, const int* block_tables,
+                               const int* context_lens, void* out, void* q_out, float* scale_out, float scale, int64_t B,
+                               int Hq, int Hkv, int head_dim, int block_size, int max_blocks, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || (B > 0 && (!q_out || !scale_out))) {
+        set_error("ql_paged_attn_decode_quant: bad argument (dtype=%d)", dtype);
+        return QL_EINVAL;
+    }
+    return paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, out, scale, B, Hq, Hkv, head_dim, block_size,
+                             max_blocks, workspace, workspace_bytes, stream, nullptr, dtype, q_out, scale_out);
 }
 
 int ql_paged_attn_decode_rowmax(const void* q, const void* k_cache, const void* v_cache, const int* block_tables,

@@ -66,6 +66,8 @@ SIGNATURES = {
     "ql_paged_attn_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
     "ql_paged_attn_decode": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64, _c_int, _c_int,
                                       _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "ql_paged_attn_decode_quant": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float,
+                                            _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "ql_paged_attn_decode_rowmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64, _c_int,
                                              _c_int, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
 }

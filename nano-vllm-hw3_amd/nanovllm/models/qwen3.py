@@ -38,6 +38,9 @@ import os as _os
 FUSE_QKV_ROPE = _os.environ.get("NANOVLLM_NO_QKV_ROPE", "") == ""
 # The output projection runs on this package's bf16 GEMM, with the greedy sampler in its epilogue where the caller
 # only wants tokens (NANOVLLM_NO_HEAD_ARGMAX=1 keeps torch's GEMM and the separate argmax launch, for A/B measurements)
+# A W8A8 o_proj takes its input already quantized from the attention merge launch (NANOVLLM_NO_ATTN_QUANT=1 keeps the
+# separate ql_quant_per_row launch, for A/B measurements; bit-identical results)
+FUSE_ATTN_QUANT = _os.environ.get("NANOVLLM_NO_ATTN_QUANT", "") == ""
 FUSE_HEAD_ARGMAX = _os.environ.get("NANOVLLM_NO_HEAD_ARGMAX", "") == ""
 
 
@@ -205,6 +208,12 @@ class Qwen3Attention(nn.Module):
                 cu_dev = torch.tensor(ctx.cu_seqlens, dtype=torch.int32, device=q.device)
             max_len = ctx.max_seqlen or max(b - a for a, b in zip(ctx.cu_seqlens[:-1], ctx.cu_seqlens[1:]))
             o = ops.attn_prefill(q, k, v, cu_dev, max_len, self.scaling)
+        elif FUSE_ATTN_QUANT and getattr(self.o_proj, "takes_quantized_input", False) and q.is_cuda:
+            # a W8A8 o_proj: the attention merge launch also quantizes every output row (the per_row_quant(x) of
+            # per_row_matmul, quantization.py:323), so the projection starts from (q, scale) with no launch in between
+            o, qx, sx = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens,
+                                              self.scaling, quant_dtype=self.o_proj.dtype)
+            return self.o_proj.forward_quantized(qx, sx)
         elif _takes_rowmax(self.o_proj):
             # a W8A8 o_proj: the attention launches also emit the partial row maxima of their output, and the
             # projection quantizes its input inside the GEMM (no per_row_quant launch in between)

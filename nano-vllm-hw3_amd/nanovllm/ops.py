@@ -107,12 +107,13 @@ def reserve_attn_workspace(max_batch, num_heads, num_kv_heads, block_size, max_b
     return n
 
 
-def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale, return_rowmax=False):
+def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale, return_rowmax=False, quant_dtype=None):
     """q [B,Hq,D]; caches [num_blocks, block_size, Hkv, D] -> out [B,Hq,D].  ``return_rowmax``: also f32 [B, Hkv],
     the |max| of every output row over each kv head's columns (the partial row maxima a W8A8 o_proj that quantizes
-    its input inside the GEMM asks for)."""
+    its input inside the GEMM asks for).  ``quant_dtype`` (torch.int8 / float8_e4m3fn): returns (out, qx, sx) with
+    the rows of out quantized as per_row_quant would, done by the merge launch."""
     if not q.is_cuda:
-        assert not return_rowmax
+        assert not return_rowmax and quant_dtype is None
         return cpu_ops.paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale)
     Q.require_cuda(q, BF16, "q")
     B, Hq, D = q.shape
@@ -121,6 +122,16 @@ def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, scale, re
     lib = Q.load()
     max_blocks = block_tables.shape[1]
     ws_ptr, ws_len = Q.attn_workspace.get(q.device, lib.ql_paged_attn_workspace_bytes(B, Hq, Hkv, block_size, max_blocks))
+    if quant_dtype is not None:
+        # a W8A8 o_proj consumes the output: the merge launch also quantizes every row (per_row_quant semantics)
+        qx = torch.empty((B, Hq * D), dtype=quant_dtype, device=q.device)
+        sx = torch.empty((B,), dtype=torch.float32, device=q.device)
+        Q.check(lib.ql_paged_attn_decode_quant(Q.QL_INT8 if quant_dtype == torch.int8 else Q.QL_FP8, q.data_ptr(),
+                                               k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                               context_lens.data_ptr(), out.data_ptr(), qx.data_ptr(), sx.data_ptr(), scale,
+                                               B, Hq, Hkv, D, block_size, max_blocks, ws_ptr, ws_len,
+                                               Q.stream_ptr(q.device)))
+        return out, qx, sx
     if return_rowmax:
         rowmax = torch.empty((B, Hkv), dtype=torch.float32, device=q.device)
         Q.check(lib.ql_paged_attn_decode_rowmax(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),

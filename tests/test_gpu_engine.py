@@ -170,6 +170,13 @@ def test_paged_attn_decode_matches_torch(G):
     # the variant that also emits partial row maxima (for a W8A8 o_proj that quantizes its input in the GEMM): same
     # outputs bit for bit; every (sequence, kv head) entry is exactly the |max| of that head group's outputs, for
     # single-chunk rows (attention launch), multi-chunk rows (merge launch) and padded rows
+    # the variant whose merge launch also quantizes the rows for a W8A8 o_proj: ql_quant_per_row's bytes and scales
+    from nanovllm.utils import quantization as NQ
+    for qd in (torch.int8, torch.float8_e4m3fn):
+        out3, qx, sx = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5, quant_dtype=qd)
+        assert torch.equal(out3, out)
+        qr, sr = NQ.per_row_quant(out.view(B, Hq * D), qd)
+        assert torch.equal(sx, sr) and torch.equal(qx.view(torch.uint8), qr.view(torch.uint8))
     rm0 = torch.full((B, Hkv), -1.0, device="cuda")
     out2, rm = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5, return_rowmax=True)
     assert torch.equal(out2, out) and rm.shape == rm0.shape
@@ -328,6 +335,24 @@ def test_w8a8_engine_without_activation_quant_launches(tiny_dir, dtype):
         NQ.w8a8_dynq_matmul = orig
         NQ.FUSE_ACT_QUANT = was
     assert out_f == out_p and out_fe == out_p
+
+
+@pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn])
+def test_w8a8_o_proj_input_quantized_by_the_attention_merge_launch(tiny_dir, dtype):
+    """Default W8A8 decode: the attention merge launch hands o_proj (q, scale) directly.  Same tokens as with the
+    separate ql_quant_per_row launch."""
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.models import qwen3
+    sp = SamplingParams(max_tokens=20, ignore_eos=True)
+    kw = dict(load_format="dummy", max_model_len=512, max_num_seqs=16, quant_type="per_row", linear_dtype=dtype)
+    assert qwen3.FUSE_ATTN_QUANT
+    out_f = [o["token_ids"] for o in LLM(tiny_dir, enforce_eager=False, **kw).generate(_prompts(6), sp)]
+    qwen3.FUSE_ATTN_QUANT = False
+    try:
+        out_p = [o["token_ids"] for o in LLM(tiny_dir, enforce_eager=True, **kw).generate(_prompts(6), sp)]
+    finally:
+        qwen3.FUSE_ATTN_QUANT = True
+    assert out_f == out_p
 
 
 def test_quantized_lm_head_opt_in(tiny_dir):
