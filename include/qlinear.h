@@ -176,6 +176,18 @@ int ql_add_rmsnorm_partial(const float* partials, int slices, int granularity, c
                            const void* residual_bf16, const void* weight_bf16, float eps, void* out_bf16,
                            void* residual_out_bf16, int64_t T, int64_t H, void* stream);
 
+/* The same pair for the W8A8 form (per_row_matmul, nanovllm/utils/quantization.py:310-346): the GEMM stores the raw
+ * slices (int32 sums for int8 x int8, f32 for fp8 x fp8; [slices][M][N], 4 bytes per element) and the norm launch
+ * adds them (integers exactly), applies (sum * sx[m]) * sw[n] (+ bias) as ql_gemm_w8a8's epilogue does, and continues
+ * as ql_add_rmsnorm (out_dtype < 0: bf16 `out`) or ql_add_rmsnorm_quant (out_dtype = QL_INT8 / QL_FP8: q_out +
+ * scale_out for the next W8A8 linear).  Bit-identical to ql_gemm_w8a8 followed by the plain norm launch. */
+int ql_gemm_w8a8_partial(int dtype, const void* qx, const void* qw, int64_t M, int64_t N, int64_t K, void* partials,
+                         int slices, void* stream);
+int ql_add_rmsnorm_partial_w8a8(int out_dtype, const void* partials, int slices, int acc_is_int, const float* sx,
+                                const float* sw, const void* bias_bf16, const void* residual_bf16,
+                                const void* weight_bf16, float eps, void* out_bf16, void* residual_out_bf16,
+                                void* q_out, float* scale_out, int64_t T, int64_t H, void* stream);
+
 /* The qkv projection with everything between it and attention fused into the GEMM epilogue
  * (Qwen3Attention.forward, nanovllm/models/qwen3.py:80-88: qkv_proj, split, q_norm / k_norm, rotary_emb, and the
  * store_kvcache of nanovllm/layers/attention.py:10-40, 52-58): the [M, N] projection is never written; every

@@ -412,6 +412,36 @@ int ql_gemm_w8a16_partial(int wdtype, int granularity, const void* x, const void
     return QL_OK;
 }
 
+int ql_gemm_w8a8_partial(int dtype, const void* qx, const void* qw, int64_t M, int64_t N, int64_t K, void* partials,
+                         int slices, void* stream) {
+    const char* fn = "ql_gemm_w8a8_partial";
+    const bool tiled = (dtype & QL_TILED) != 0;
+    dtype &= ~QL_TILED;
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || (M > 0 && (!qx || !partials)) || !qw) {
+        set_error("%s: bad argument (dtype=%d)", fn, dtype);
+        return QL_EINVAL;
+    }
+    if (int rc = check_common(fn, M, N, K)) return rc;
+    if (M == 0) return QL_OK;
+    const Plan pl = make_plan_partial(M, N, K, false);
+    if (slices != pl.split) {
+        set_error("%s: slices=%d, but the plan for M=%lld N=%lld K=%lld has %d (ql_gemm_partial_slices)", fn, slices,
+                  (long long)M, (long long)N, (long long)K, pl.split);
+        return QL_EINVAL;
+    }
+    GemmParams p{};
+    p.x = (const unsigned char*)qx; p.w = (const unsigned char*)qw;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.wtiled = tiled ? 1 : 0;
+    p.partial_rm = (float*)partials;
+    p.k_per_split = pl.k_per_split;
+    kern_t k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp);
+    if (!k) { set_error("%s: tile (%d,%d,%d,%d) not built", fn, pl.mt, pl.wn, pl.wk, pl.cp); return QL_EINVAL; }
+    hipLaunchKernelGGL(k, pl.grid, dim3(64 * pl.wn * pl.wk), 0, as_stream(stream), p);
+    QL_CHECK_LAUNCH(fn);
+    return QL_OK;
+}
+
 int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
                        void* y, int64_t M, int64_t N, int64_t K, int group, void* stream) {
     return gemm_w8a16("ql_gemm_w8a16_silu", true, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, nullptr, 0,

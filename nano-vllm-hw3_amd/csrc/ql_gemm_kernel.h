@@ -47,7 +47,7 @@ struct GemmParams {
     unsigned short* y;           // [M,N] bf16
     unsigned* counters;          // [tiles] zero before the call, zero again after it (split-K only)
     void* partial;               // [tiles][S][WN][MT][16][64] f32 / i32 slabs (split-K only)
-    float* partial_rm;           // deferred reduction (W8A16 only): [S][M][N] f32, slice z stores its unscaled partial
+    float* partial_rm;           // deferred reduction: [S][M][N] f32 (int32 for int8 x int8), slice z stores its unscaled partial
                                  // sums row-major and the NEXT launch (ql_add_rmsnorm_partial) adds the slices up
     int M, N, K;
     int group;                   // group size (per-group only)
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     const int n = n0 + l31;
     const bool nvalid = n < p.N;
     float sw = 1.f, bias = 0.f;
-    if (!GROUP && !W16 && nvalid) sw = p.sw[(size_t)n * p.sw_stride];
+    if (!GROUP && !W16 && nvalid && p.sw) sw = p.sw[(size_t)n * p.sw_stride];   // (null: a deferred W8A8 launch, scaled by its consumer)
     const bool has_bias = p.bias != nullptr;
     if (has_bias && nvalid) bias = bf16_bits_to_f32(p.bias[n]);
 
@@ -593,23 +593,22 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
                     acc[i][R0 + rr] = sum;
                 }
         }
-        if constexpr (!INT) {
-            if (p.partial_rm) {
-                // deferred reduction: no ticket, no second pass here.  The consumer launch sums the slices in slice
-                // order and applies the epilogue, which takes two dependent memory round trips (ticket, slab
-                // reads) out of this kernel and lets K be cut as finely as the chip needs workgroups.
-                if (!nvalid) return;
-                float* dst = p.partial_rm + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N + n;
+        if (p.partial_rm) {
+            // deferred reduction: no ticket, no second pass here.  The consumer launch sums the slices in slice
+            // order and applies the epilogue, which takes two dependent memory round trips (ticket, slab
+            // reads) out of this kernel and lets K be cut as finely as the chip needs workgroups.
+            // (int8 x int8: the slabs hold the int32 sums themselves, so the consumer adds integers exactly)
+            if (!nvalid) return;
+            raw_t* dst = (raw_t*)p.partial_rm + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N + n;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < RN; ++rr) {
-                        const int r = R0 + rr;
-                        const int row = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < p.M) dst[(size_t)row * p.N] = (float)acc[i][r];
-                    }
-                return;
-            }
+                for (int rr = 0; rr < RN; ++rr) {
+                    const int r = R0 + rr;
+                    const int row = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < p.M) dst[(size_t)row * p.N] = (raw_t)acc[i][r];
+                }
+            return;
         }
         if (S > 1) {
             // split-K across workgroups: slab store, ticket, the last arriver sums the slabs in slice order

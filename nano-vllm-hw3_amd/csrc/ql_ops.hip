@@ -27,6 +27,8 @@ struct PartialSrc {
     const unsigned short* bias;   // [H] bf16 or null
     int64_t slab;                 // T * H
     int S, sw_stride, bias_after_round;
+    const float* sx;              // W8A8: per-token activation scales [T], applied before sw; else null
+    int is_int;                   // the slabs hold int32 sums (int8 x int8): added as integers, converted once
 };
 
 template <int NV, int QDT>   // 16-byte vectors per thread
@@ -65,8 +67,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
                 }
                 if (ps.bias) bb = *(const u16x8*)(ps.bias + c * 8);
                 float acc[8];
+                int acci[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+                for (int k = 0; k < 8; ++k) { acc[k] = 0.f; acci[k] = 0; }
+                const float sxr = ps.sx ? ps.sx[row] : 1.f;
                 const float* src = ps.part + row * H + c * 8;
                 for (int s0 = 0; s0 < ps.S; s0 += 4) {
                     float4 p0[4], p1[4];
@@ -79,9 +83,24 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (s0 + u < ps.S) {
-                            acc[0] += p0[u].x; acc[1] += p0[u].y; acc[2] += p0[u].z; acc[3] += p0[u].w;
-                            acc[4] += p1[u].x; acc[5] += p1[u].y; acc[6] += p1[u].z; acc[7] += p1[u].w;
+                            if (ps.is_int) {
+                                acci[0] += __builtin_bit_cast(int, p0[u].x); acci[1] += __builtin_bit_cast(int, p0[u].y);
+                                acci[2] += __builtin_bit_cast(int, p0[u].z); acci[3] += __builtin_bit_cast(int, p0[u].w);
+                                acci[4] += __builtin_bit_cast(int, p1[u].x); acci[5] += __builtin_bit_cast(int, p1[u].y);
+                                acci[6] += __builtin_bit_cast(int, p1[u].z); acci[7] += __builtin_bit_cast(int, p1[u].w);
+                            } else {
+                                acc[0] += p0[u].x; acc[1] += p0[u].y; acc[2] += p0[u].z; acc[3] += p0[u].w;
+                                acc[4] += p1[u].x; acc[5] += p1[u].y; acc[6] += p1[u].z; acc[7] += p1[u].w;
+                            }
                         }
+                }
+                if (ps.is_int) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = (float)acci[k];
+                }
+                if (ps.sx) {                  // the W8A8 epilogue: (sum * sx[m]) * sw[n], in that order
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = __fmul_rn(acc[k], sxr);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -531,6 +550,24 @@ int ql_add_rmsnorm_partial(const float* partials, int slices, int granularity, c
     ps.bias = (const unsigned short*)bias;
     ps.bias_after_round = granularity == QL_PER_ROW ? 0 : 1;
     return add_rmsnorm_launch(fn, -1, nullptr, residual, weight, eps, out, residual_out, nullptr, nullptr, T, H, stream, ps);
+}
+
+int ql_add_rmsnorm_partial_w8a8(int out_dtype, const void* partials, int slices, int acc_is_int, const float* sx,
+                                const float* sw, const void* bias, const void* residual, const void* weight, float eps,
+                                void* out, void* residual_out, void* q_out, float* scale_out, int64_t T, int64_t H,
+                                void* stream) {
+    const char* fn = "ql_add_rmsnorm_partial_w8a8";
+    if (!partials || slices < 1 || !sx || !sw || !residual || !residual_out) {
+        set_error("%s: bad argument (a deferred GEMM output always joins a residual)", fn);
+        return QL_EINVAL;
+    }
+    PartialSrc ps{};
+    ps.part = (const float*)partials; ps.S = slices; ps.slab = T * H;
+    ps.sw = sw; ps.sw_stride = 1;
+    ps.bias = (const unsigned short*)bias; ps.bias_after_round = 0;
+    ps.sx = sx; ps.is_int = acc_is_int ? 1 : 0;
+    return add_rmsnorm_launch(fn, out_dtype, nullptr, residual, weight, eps, out, residual_out, q_out, scale_out, T, H,
+                              stream, ps);
 }
 
 int ql_silu_mul(const void* x, void* out, int64_t T, int64_t I, void* stream) {

@@ -55,6 +55,9 @@ SIGNATURES = {
                                       _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_vp]),
     "ql_argmax_rows": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_row_absmax_parts": (_c_int, [_c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp]),
+    "ql_gemm_w8a8_partial": (_c_int, [_c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_vp]),
+    "ql_add_rmsnorm_partial_w8a8": (_c_int, [_c_int, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float,
+                                             _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_gemm_w8a8_silu_rowmax": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ql_gemm_w8a8_dynq": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
                                    _c_sz, _c_vp]),

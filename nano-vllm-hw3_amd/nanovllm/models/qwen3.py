@@ -213,7 +213,7 @@ class Qwen3Attention(nn.Module):
             # per_row_matmul, quantization.py:323), so the projection starts from (q, scale) with no launch in between
             o, qx, sx = ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens,
                                               self.scaling, quant_dtype=self.o_proj.dtype)
-            return self.o_proj.forward_quantized(qx, sx)
+            return self.o_proj.forward_partial_quantized(qx, sx)
         elif _takes_rowmax(self.o_proj):
             # a W8A8 o_proj: the attention launches also emit the partial row maxima of their output, and the
             # projection quantizes its input inside the GEMM (no per_row_quant launch in between)

@@ -32,12 +32,29 @@ def add_rmsnorm(x, residual, weight, eps):
     return out, res_out
 
 
-def _add_rmsnorm_partial(ps, residual, weight, eps):
+def _add_rmsnorm_partial(ps, residual, weight, eps, quant_dtype=None):
+    """The launch that finishes a deferred GEMM: (normed, new_residual), or with ``quant_dtype`` (a W8A8 linear
+    follows) (q, scale, new_residual)."""
     assert residual is not None, "a deferred GEMM output always joins a residual"
     Q.require_cuda(residual, BF16, "residual")
     S, T, H = ps.parts.shape
-    out = torch.empty(ps.shape, dtype=BF16, device=residual.device)
-    res_out = torch.empty_like(out)
+    res_out = torch.empty(ps.shape, dtype=BF16, device=residual.device)
+    if getattr(ps, "sx", None) is not None:                    # W8A8: raw int32 / f32 slices + both scale vectors
+        out = q = scale = None
+        if quant_dtype is None:
+            out = torch.empty_like(res_out)
+        else:
+            q = torch.empty((T, H), dtype=quant_dtype, device=residual.device)
+            scale = torch.empty((T,), dtype=torch.float32, device=residual.device)
+        Q.check(Q.load().ql_add_rmsnorm_partial_w8a8(
+            -1 if quant_dtype is None else Q.dtype_code(quant_dtype), ps.parts.data_ptr(), S, 1 if ps.is_int else 0,
+            ps.sx.data_ptr(), ps.sw.data_ptr(), ps.bias.data_ptr() if ps.bias is not None else None, residual.data_ptr(),
+            weight.data_ptr(), eps, out.data_ptr() if out is not None else None, res_out.data_ptr(),
+            q.data_ptr() if q is not None else None, scale.data_ptr() if scale is not None else None, T, H,
+            Q.stream_ptr(residual.device)))
+        return (out, res_out) if quant_dtype is None else (q, scale, res_out)
+    assert quant_dtype is None, "weight-only partial sums feed a bf16 norm output"
+    out = torch.empty_like(res_out)
     Q.check(Q.load().ql_add_rmsnorm_partial(ps.parts.data_ptr(), S, ps.granularity, ps.sw.data_ptr(),
                                             ps.bias.data_ptr() if ps.bias is not None else None, residual.data_ptr(),
                                             weight.data_ptr(), eps, out.data_ptr(), res_out.data_ptr(), T, H,
@@ -47,7 +64,9 @@ def _add_rmsnorm_partial(ps, residual, weight, eps):
 
 def add_rmsnorm_quant(x, residual, weight, eps, dtype):
     """add_rmsnorm + per-row activation quantization in one launch: returns (q, scale, new_residual) with
-    (q, scale) bit-identical to per_row_quant(add_rmsnorm(...)[0], dtype)."""
+    (q, scale) bit-identical to per_row_quant(add_rmsnorm(...)[0], dtype).  x may be a W8A8 PartialSum."""
+    if hasattr(x, "parts"):
+        return _add_rmsnorm_partial(x, residual, weight, eps, quant_dtype=dtype)
     Q.require_cuda(x, BF16, "x")
     H = x.shape[-1]
     T = x.numel() // H

@@ -286,11 +286,30 @@ class PartialSum:
     launch that consumes it (ops.add_rmsnorm accepts it in place of x): ``parts`` [S, M, N] f32 unscaled partial
     sums, plus the scale / bias the epilogue applies."""
 
-    def __init__(self, parts, granularity, sw, bias, shape):
+    def __init__(self, parts, granularity, sw, bias, shape, sx=None, is_int=False):
         self.parts, self.granularity, self.sw, self.bias, self.shape = parts, granularity, sw, bias, shape
+        self.sx, self.is_int = sx, is_int      # W8A8: per-token activation scales; int32 slices (int8 x int8)
 
     def dim(self):
         return len(self.shape)
+
+
+@torch.no_grad()
+def w8a8_partial_matmul(mod, qx, sx):
+    """``mod`` (a W8A8 QLinear) applied to per-row quantized activations with the split-K reduction and the dual-
+    scale epilogue deferred: a PartialSum of raw slices (int32 for int8, f32 for fp8) plus both scale vectors."""
+    lib = Q.load()
+    dtype = mod.dtype
+    N, K = mod.qw.shape
+    Q.require_cuda(qx, dtype, "qx")
+    Q.require_cuda(sx, torch.float32, "sx")
+    M = qx.shape[0]
+    S = lib.ql_gemm_partial_slices(M, N, K, Q.QL_PER_ROW)
+    is_int = dtype == torch.int8
+    parts = torch.empty((max(S, 1), M, N), dtype=torch.int32 if is_int else torch.float32, device=qx.device)
+    Q.check(lib.ql_gemm_w8a8_partial(_wcode(mod.qw, dtype), qx.data_ptr(), mod.qw.data_ptr(), M, N, K, parts.data_ptr(), S,
+                                     Q.stream_ptr(qx.device)))
+    return PartialSum(parts, Q.QL_PER_ROW, mod.sw, mod._bias_for_rank(), (M, N), sx=sx, is_int=is_int)
 
 
 @torch.no_grad()
@@ -448,6 +467,9 @@ class _QBase(torch.nn.Module):
         the norm launch finishes; otherwise the plain output."""
         weight_only = not isinstance(self, QLinear) or self.weight_only
         m = x.numel() // x.shape[-1]
+        if not weight_only and x.dim() == 2 and x.is_cuda:
+            # W8A8: quantize the activations (their own launch), then the deferred form where it pays
+            return self.forward_partial_quantized(*per_row_quant(x.contiguous(), self.dtype))
         if (DEFER_SPLITK and weight_only and not self.silu_fused and not (self.tp_dim == 1 and self.tp_size > 1)
                 and 0 < m <= self.PARTIAL_MAX_ROWS and x.dim() == 2):
             gran = Q.QL_PER_GROUP if isinstance(self, QGroupLinear) else Q.QL_PER_TENSOR if isinstance(self, QTensorLinear) else Q.QL_PER_ROW
@@ -531,6 +553,17 @@ class QLinear(_QBase):
         return self._run(qx, lambda rows, out: w8a8_matmul(
             qx if rows is None else qx[rows], sx if rows is None else sx[rows], self.qw, self.sw,
             self._bias_for_rank(), self.dtype, None, self.silu_fused, out))
+
+    def forward_partial_quantized(self, qx: torch.Tensor, sx: torch.Tensor):
+        """forward_quantized() for a projection whose output goes straight into ops.add_rmsnorm /
+        ops.add_rmsnorm_quant: at decode sizes, without a tensor-parallel all-reduce in between and when the plan has
+        K slices to defer, a PartialSum that the norm launch finishes; otherwise the plain output."""
+        m = qx.shape[0]
+        if (DEFER_SPLITK and not self.weight_only and not self.silu_fused and not (self.tp_dim == 1 and self.tp_size > 1)
+                and 0 < m <= self.PARTIAL_MAX_ROWS
+                and Q.load().ql_gemm_partial_slices(m, self.qw.shape[0], self.qw.shape[1], Q.QL_PER_ROW) > 1):
+            return w8a8_partial_matmul(self, qx, sx)
+        return self.forward_quantized(qx, sx)
 
     def forward_with_rowmax(self, x: torch.Tensor, rowmax_part: torch.Tensor):
         """forward() of the W8A8 form on bf16 activations whose partial row maxima the producing kernel emitted

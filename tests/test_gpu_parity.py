@@ -509,7 +509,8 @@ def test_deferred_splitk_full_size_own_plan(NQ, nk, M):
         d = (a.float() - b.float()).abs()
         assert (d <= 2.0 ** -6 * b.float().abs() + 2e-2).all()
         assert (a == b).float().mean() > 0.9
-    assert torch.is_tensor(NQ.QLinear(torch.int8, w, None).tile().forward_partial(x))          # W8A8: self-contained
+    w8a8 = NQ.QLinear(torch.int8, w, None).tile().forward_partial(x)          # W8A8 defers too (its own test below)
+    assert torch.is_tensor(w8a8) or w8a8.sx is not None
     big = torch.randn(mod.PARTIAL_MAX_ROWS + 1, K, device="cuda", dtype=torch.bfloat16)
     assert torch.is_tensor(mod.forward_partial(big))
 
@@ -861,3 +862,71 @@ def test_w8a8_mlp_without_a_quantization_launch(NQ, dt, M, tile):
     assert rm.shape == (M, 2 * I // 64)
     assert torch.equal(rm, y.float().abs().view(M, I // 32, 32).amax(-1))
     assert torch.equal(NQ.w8a8_dynq_matmul(y, rm, qd, sd, None, tdt), NQ.per_row_matmul(y, qd, sd, None, tdt))
+
+
+@pytest.mark.parametrize("tile", [(1, 1, 8, 4), (1, 1, 4, 4), (1, 2, 4, 8), (2, 2, 4, 8), (2, 4, 2, 4)])
+@pytest.mark.parametrize("split", [1, 2, 5])
+def test_w8a8_deferred_splitk_norm_bit_identical(NQ, tile, split):
+    """The W8A8 form of the deferred split-K: raw slices (int32 sums for int8 x int8, f32 for fp8 x fp8) finished
+    by the residual add + RMSNorm launch with the dual-scale epilogue, == ql_gemm_w8a8 (same tile, same slices)
+    followed by ql_add_rmsnorm / ql_add_rmsnorm_quant, bit for bit; with and without a bias, M and N tails, a
+    ragged last slice."""
+    from nanovllm import _qlinear as Q, ops
+    lib = Q.load()
+    M, N, K = 70, 200, 1184
+    rng = np.random.default_rng(33)
+    x = bf16_t(rand_bf16(rng, (M, K)))
+    w = bf16_t(rand_bf16(rng, (N, K), 0.05))
+    bias = torch.nn.Parameter(bf16_t(rand_bf16(rng, (N,), 0.5)), requires_grad=False)
+    res = bf16_t(rand_bf16(rng, (M, N)))
+    nw = bf16_t(O.f32_to_bf16((1 + 0.1 * rng.standard_normal(N)).astype(np.float32)))
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], split) == 0
+        for tdt, b in ((torch.int8, None), (torch.int8, bias), (torch.float8_e4m3fn, None), (torch.float8_e4m3fn, bias)):
+            mod = NQ.QLinear(tdt, w, b).tile()
+            qx, sx = NQ.per_row_quant(x, tdt)
+            ps = NQ.w8a8_partial_matmul(mod, qx, sx)
+            assert ps.parts.shape == (lib.ql_gemm_partial_slices(M, N, K, Q.QL_PER_ROW), M, N)
+            assert ps.parts.dtype == (torch.int32 if tdt == torch.int8 else torch.float32)
+            y = mod.forward_quantized(qx, sx)
+            out, new_res = ops.add_rmsnorm(ps, res, nw, 1e-6)
+            ref_out, ref_res = ops.add_rmsnorm(y, res, nw, 1e-6)
+            assert torch.equal(new_res, ref_res) and torch.equal(out, ref_out), (tile, split, tdt)
+            for qd in (torch.int8, torch.float8_e4m3fn):
+                q1, s1, r1 = ops.add_rmsnorm_quant(ps, res, nw, 1e-6, qd)
+                q0, s0, r0 = ops.add_rmsnorm_quant(y, res, nw, 1e-6, qd)
+                assert torch.equal(q1.view(torch.uint8), q0.view(torch.uint8)) and torch.equal(s1, s0) and torch.equal(r1, r0)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("dt", ["int8", "fp8"])
+@pytest.mark.parametrize("nk", [(1024, 2048), (1024, 3072)])
+@pytest.mark.parametrize("M", [1, 16, 130, 256, 512, 600])
+def test_w8a8_deferred_splitk_module_route(NQ, dt, nk, M):
+    """QLinear.forward_partial_quantized at the o_proj / down_proj shapes: a PartialSum where the plan has slices to
+    defer (decode sizes), the plain output otherwise; either way the norm that follows agrees with the plain route
+    (the two routes slice K differently: int8 sums are exact, so int8 is bit-identical; fp8 to the GEMM's rounding)."""
+    from nanovllm import ops
+    tdt = TDT[dt]
+    N, K = nk
+    g = torch.Generator(device="cuda").manual_seed(N + K + M)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda", dtype=torch.bfloat16, generator=g)
+    nw = torch.ones(N, device="cuda", dtype=torch.bfloat16)
+    mod = NQ.QLinear(tdt, w, None).tile()
+    qx, sx = NQ.per_row_quant(x, tdt)
+    y = mod.forward_partial_quantized(qx, sx)
+    from nanovllm import _qlinear as Q
+    slices = Q.load().ql_gemm_partial_slices(M, N, K, Q.QL_PER_ROW)
+    assert hasattr(y, "parts") == (M <= 512 and slices > 1)
+    if M in (1, 16):
+        assert hasattr(y, "parts")                       # small decode batches do defer at these shapes
+    out, new_res = ops.add_rmsnorm(y, res, nw, 1e-6)
+    ref_out, ref_res = ops.add_rmsnorm(mod.forward_quantized(qx, sx), res, nw, 1e-6)
+    if dt == "int8":
+        assert torch.equal(out, ref_out) and torch.equal(new_res, ref_res)
+    else:
+        d = (out.float() - ref_out.float()).abs()
+        assert (d <= 2.0 ** -6 * ref_out.float().abs() + 2e-2).all()
