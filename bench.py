@@ -202,8 +202,10 @@ def measure_decode_gemm(llm, step_batches):
 
 def measure_prefill_gemm(llm, M=16384):
     """MFMA-bound side of the same kernel: the four layer GEMMs at a prefill-sized batch (M = the scheduler's
-    max_num_batched_tokens), HIP events around 5 back-to-back rounds; achieved = 2*M*N*K flop / time against
-    the dense bf16 MFMA peak (the W8A16 kernel contracts on bf16 MFMA after widening the weights)."""
+    max_num_batched_tokens), HIP events around 20 back-to-back rounds after 40 untimed ones (the leg follows the
+    latency-bound decode legs, and the first ~10 ms of MFMA-bound work run at the clocks those left behind: a
+    5-round measurement read 5-10 % low); achieved = 2*M*N*K flop / time against the dense bf16 MFMA peak (the W8A16
+    kernel contracts on bf16 MFMA after widening the weights)."""
     from nanovllm.utils.quantization import QLinear
     l0 = llm.model_runner.model.model.layers[0]
     mods = [l0.self_attn.qkv_proj, l0.self_attn.o_proj, l0.mlp.gate_up_proj, l0.mlp.down_proj]
@@ -211,17 +213,18 @@ def measure_prefill_gemm(llm, M=16384):
         return None
     with torch.inference_mode():
         xs = [torch.randn(M, m.qw.shape[1], device="cuda", dtype=torch.bfloat16) for m in mods]
-        for x, m in zip(xs, mods):
-            m(x)
+        for _ in range(40):
+            for x, m in zip(xs, mods):
+                m(x)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(5):
+        for _ in range(20):
             for x, m in zip(xs, mods):
                 m(x)
         e.record()
         torch.cuda.synchronize()
-    t = s.elapsed_time(e) * 1e-3 / 5
+    t = s.elapsed_time(e) * 1e-3 / 20
     flop = sum(2.0 * M * m.qw.shape[0] * m.qw.shape[1] for m in mods)
     tf = flop / t / 1e12
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),

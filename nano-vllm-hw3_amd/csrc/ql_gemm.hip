@@ -27,7 +27,7 @@ static bool rope_tile_built(int mt, int wn, int wk, int cp) {
 
 struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; bool pair_rows = false; };
 
-static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false, bool rope = false) {
+static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false, bool rope = false, bool w8a8 = false) {
     Plan pl;
     // Tile ladder, smallest to largest output tile.  On a 256-CU chip these GEMMs are bound by
     // instruction issue and L2->LDS traffic per workgroup, not by HBM or MFMA peak, so the measured
@@ -73,7 +73,13 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
         // per MFMA (measured +25 % at M = 16384); 128-k chunks give its loads a whole chunk of MFMAs to land.
         // Per-group scales keep a second accumulator set, which fits beside 64-k chunks only (measured -24 % at
         // M = 16384 against the 64 x 128 tile, and ahead of the 128-k form on every shape).
-        if (((M + 127) / 128) * ((N + 255) / 256) >= 256) { mt = 4; wn = 8; wk = 1; cp = group ? 2 : 4; }
+        const int64_t wide = ((M + 127) / 128) * ((N + 255) / 256);
+        if (wide >= 256) { mt = 4; wn = 8; wk = 1; cp = group ? 2 : 4; }
+        // Two rounds of those tiles or more and K up to 2048 (bf16 activations, per-row / per-tensor scales): the
+        // 64-k-chunk form of the tile, built to 128 registers so that two workgroups share a CU and one's prologue
+        // and epilogue overlap the other's main loop (measured at M = 16384: qkv +14 %, gate_up +8 %, o_proj +4 %;
+        // down_proj, K = 3072, keeps the 128-k chunks with the two-chunk-deep prefetch: -3 % otherwise)
+        if (wide >= 512 && K <= 2048 && !group && !w8a8) cp = 2;
     }
     if (rope) {
         // the q/k norm + RoPE epilogue needs whole 128-column heads in one workgroup (4 or 8 column strips).
@@ -331,7 +337,7 @@ static int gemm_w8a8(const char* fn, bool silu, int dtype, const void* qx, const
     if (rope) { p.rope_on = 1; p.rope = *rope; }
     p.rowmax_part = rowmax_part; p.nparts = nparts;
     p.rowmax_out = silu ? rowmax_out : nullptr; p.nparts_out = (int)(N / 64);
-    const Plan pl = make_plan(M, N, K, false, silu, rope != nullptr);
+    const Plan pl = make_plan(M, N, K, false, silu, rope != nullptr, true);
     kern_t k;
     if (dynq) k = dtype == QL_INT8 ? pick_i8_i8_dynq(pl.mt, pl.wn, pl.wk, pl.cp) : pick_fp8_fp8_dynq(pl.mt, pl.wn, pl.wk, pl.cp);
     else k = dtype == QL_INT8 ? pick_i8_i8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr) : pick_fp8_fp8(pl.mt, pl.wn, pl.wk, pl.cp, rope != nullptr);

@@ -154,7 +154,11 @@ struct Cfg {
 
 template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP, bool ROPE = false, bool W16 = false,
           bool AMAX = false, bool DYNQ = false>
-__global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p) {
+// (second launch bound = waves per SIMD the register allocation must leave room for: the 128 x 256 weight-only tile
+// with 64-k chunks is held to 128 registers so that TWO of its 8-wave workgroups share a CU and one's prologue and
+// epilogue run under the other's MFMAs - worth more on the K <= 2048 shapes than the registers it gives up)
+__global__ __launch_bounds__(64 * WN * WK, (ACT == ACT_BF16 && MT == 4 && WN == 8 && WK == 1 && CP == 2 && !GROUP && !W16) ? 4 : 1)
+void qgemm_kernel(const GemmParams p) {
     static_assert(!ROPE || WN == 4 || WN == 8, "the qkv epilogue needs whole 128-column heads per workgroup");
     static_assert(!W16 || (ACT == ACT_BF16 && !GROUP && !ROPE && !FP8W), "16-bit weights: plain bf16 x bf16");
     static_assert(!AMAX || (W16 && WK == 1 && WN >= 4), "the sampler epilogue is built for the output projection's tiles");
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64 * WN * WK) void qgemm_kernel(const GemmParams p)
     // ahead.  Every chunk ends on a workgroup barrier behind the slowest of its 4096 16-byte requests, and with long
     // K slices one chunk of lead does not cover that tail; a second register set per operand buys a second chunk of
     // lead, while two LDS buffers still suffice.
-    constexpr bool DEEP = DB && WN == 8 && ACT == ACT_BF16 && !W16;
+    constexpr bool DEEP = DB && WN == 8 && ACT == ACT_BF16 && !W16 && (CP >= 4 || GROUP);
     wreg_t wcur[D], wnext[(DB && WN != 8) ? CP : 1], wcur2[DEEP ? CP : 1];
     xreg_t sreg[C::NP], sreg2[DEEP ? C::NP : 1];
     auto xload = [&](const unsigned char* ptr) -> xreg_t {
