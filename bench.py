@@ -306,6 +306,7 @@ def main():
     if args.quant_lm_head:
         kw.update(quantize_lm_head=True)
     decode_mode = "hipGraph decode"
+    llm, capture_error = None, None
     try:
         llm = LLM(model_dir, **kw)
     except Exception as ex:  # noqa: BLE001
@@ -313,14 +314,17 @@ def main():
             raise
         # Tensor-parallel ranks only: a collective that this RCCL build cannot capture into a hipGraph fails the
         # capture on every rank alike; the curve is then measured with eager decode steps, and the line says so.
-        print(f"[rank {rank}] graph capture failed ({type(ex).__name__}: {ex}); falling back to eager decode",
+        capture_error = type(ex).__name__
+        print(f"[rank {rank}] graph capture failed ({capture_error}: {ex}); falling back to eager decode",
               file=sys.stderr, flush=True)
+    if llm is None:
+        # (outside the handler: the exception's traceback keeps the first engine - weights, KV cache - alive)
         import gc
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         kw["enforce_eager"] = True
-        decode_mode = f"EAGER decode (graph capture failed: {type(ex).__name__})"
+        decode_mode = f"EAGER decode (graph capture failed: {capture_error})"
         llm = LLM(model_dir, **kw)
 
     prompts, max_tokens = workload()
