@@ -34,6 +34,12 @@ QWEN3_06B = dict(architectures=["Qwen3ForCausalLM"], hidden_size=1024, num_hidde
                  num_key_value_heads=8, head_dim=128, intermediate_size=3072, vocab_size=151936, rms_norm_eps=1e-6,
                  rope_theta=1000000.0, max_position_embeddings=40960, tie_word_embeddings=True, attention_bias=False,
                  hidden_act="silu", torch_dtype="bfloat16", eos_token_id=151645)
+# the other models BASELINE.json's configurations name (experiments: `--model 4b --quant per_group`); the headline
+# line is always Qwen3-0.6B
+QWEN3_4B = dict(QWEN3_06B, hidden_size=2560, num_hidden_layers=36, num_attention_heads=32, intermediate_size=9728)
+QWEN3_8B = dict(QWEN3_06B, hidden_size=4096, num_hidden_layers=36, num_attention_heads=32, intermediate_size=12288,
+                tie_word_embeddings=False)
+MODELS = {"0.6b": ("Qwen3-0.6B", QWEN3_06B), "4b": ("Qwen3-4B", QWEN3_4B), "8b": ("Qwen3-8B", QWEN3_8B)}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak
 
 
@@ -272,6 +278,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--quant-lm-head", action="store_true", help="opt-in int8 LM head (not the reference's numerics)")
     ap.add_argument("--max-model-len", type=int, default=4096, help="4096 = the reference bench; other values are experiments")
+    ap.add_argument("--model", default="0.6b", choices=sorted(MODELS),
+                    help="0.6b = the headline benchmark; the larger models are experiments on the same workload")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (ranks share devices)")
     args = ap.parse_args()
@@ -298,7 +306,7 @@ def main():
     from nanovllm import LLM, SamplingParams
     model_dir = tempfile.mkdtemp(prefix=f"qwen3_06b_r{rank}_")
     with open(os.path.join(model_dir, "config.json"), "w") as f:
-        json.dump(QWEN3_06B, f)
+        json.dump(MODELS[args.model][1], f)
     kw = dict(enforce_eager=False, max_model_len=args.max_model_len, load_format="dummy", tensor_parallel_size=world)
     if args.quant != "bf16":
         kw.update(quant_type=args.quant, linear_dtype=torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn,
@@ -364,7 +372,8 @@ def main():
     roof = roof_prefill = None
     # (one GPU only: under tensor parallelism the row-parallel modules' forward contains a collective, which one
     # rank must not issue alone)
-    if rank == 0 and world == 1 and not args.no_roofline and args.quant != "bf16":
+    model_name = MODELS[args.model][0]
+    if rank == 0 and world == 1 and not args.no_roofline and args.quant != "bf16" and args.model == "0.6b":
         roof = measure_decode_gemm(llm, step_batches[: len(step_batches) // max(args.steps, 1)])
         roof_prefill = measure_prefill_gemm(llm)
     cpu = None
@@ -373,12 +382,12 @@ def main():
     if rank == 0:
         dtype = "bf16" if args.quant in ("bf16", "per_row_weight_only", "per_group", "per_tensor") else args.dtype
         line = {
-            "metric": "tokens/s Qwen3-0.6B INT8, 256 seqs (bench.py)", "value": round(args.steps * total_tokens / dt, 1),
+            "metric": f"tokens/s {model_name} INT8, 256 seqs (bench.py)", "value": round(args.steps * total_tokens / dt, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "reference bench.py: 256 seqs, prompts 100-1024 random tokens, 100-1024 new tokens "
-                                   "(133,966 output tokens), Qwen3-0.6B random-init, "
+                                   f"(133,966 output tokens), {model_name} random-init, "
                                    f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, {decode_mode}",
                        "parallelism": f"tp{world}", "decode_steps": len(step_batches) // max(args.steps, 1)},
             "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,

@@ -214,6 +214,27 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
  * workspace size that ql_gemm_workspace_bytes reports while the configuration is forced. */
 int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k);
 
+/* Plan table (no counterpart in the reference: its Triton kernel runs one fixed 128 x 128 x 128 block
+ * configuration, nanovllm/utils/quantization.py:324-330): tile and split choices measured on the
+ * device for a given launch form, (N, K) and range of row counts m_lo..m_hi take precedence over the
+ * built-in heuristics for every later GEMM call of the process (ql_gemm_force_config still wins).
+ * `form` is a combination of the bits below: the scale granularity, the epilogue and the arithmetic of
+ * the launch (0 = plain per-row / per-tensor W8A16).  With QL_PLAN_PARTIAL the entry is for the deferred
+ * split-K form (ql_gemm_*_partial; split_k = 1 there means "do not defer").  Entries of one form and
+ * shape must not overlap; a tile that is not built for the form, or a split the form cannot run, is
+ * QL_EINVAL.  ql_gemm_workspace_bytes / _max_bytes see the table, so set entries before sizing a
+ * workspace.  ql_gemm_plan_query writes {mt, wn, wk, cp, split_k} of the plan a call would run to out[5]. */
+#define QL_PLAN_GROUP 1    /* per-group scales */
+#define QL_PLAN_SILU 2     /* ql_gemm_*_silu */
+#define QL_PLAN_ROPE 4     /* ql_gemm_*_rope */
+#define QL_PLAN_W8A8 8     /* ql_gemm_w8a8* (else ql_gemm_w8a16*) */
+#define QL_PLAN_PARTIAL 16 /* ql_gemm_*_partial */
+int ql_gemm_plan_set(int form, int64_t m_lo, int64_t m_hi, int64_t N, int64_t K, int mt, int wn, int wk, int cp,
+                     int split_k);
+void ql_gemm_plan_clear(void);
+int ql_gemm_plan_count(void);
+int ql_gemm_plan_query(int form, int64_t M, int64_t N, int64_t K, int* out);
+
 /* ---- operators between the quantized GEMMs of a decoder layer (one launch each) ------------- */
 
 /* RMSNorm.rms_forward / add_rms_forward (nanovllm/layers/layernorm.py:16-40): with `residual`,

@@ -2,6 +2,12 @@
 // and the extern "C" entry points.  The kernels live in ql_gemm_kernel.h / ql_gemm_inst_*.hip.
 #include "ql_gemm_kernel.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <shared_mutex>
+#include <tuple>
+#include <vector>
 
 namespace ql {
 
@@ -26,6 +32,24 @@ static bool rope_tile_built(int mt, int wn, int wk, int cp) {
 }
 
 struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; bool pair_rows = false; };
+
+// ---- plan table -------------------------------------------------------------------------------------------------
+// Tile and split choices MEASURED on the device for given shapes (tools/autotune_plans.py) take precedence over the
+// heuristics below, which were tuned on the Qwen3-0.6B layer shapes and leave 10-30 % on larger ones.  An entry
+// covers one launch form (QL_PLAN_* bits of include/qlinear.h), one (N, K) and a range of row counts.
+struct PlanEntry { int64_t m_lo, m_hi; int mt, wn, wk, cp, split; };
+static std::map<std::tuple<int, int64_t, int64_t>, std::vector<PlanEntry>> g_plans;
+static std::shared_mutex g_plans_mu;
+
+static bool plan_lookup(int form, int64_t M, int64_t N, int64_t K, PlanEntry* out) {
+    std::shared_lock<std::shared_mutex> lock(g_plans_mu);
+    if (g_plans.empty()) return false;
+    const auto it = g_plans.find(std::make_tuple(form, N, K));
+    if (it == g_plans.end()) return false;
+    for (const PlanEntry& e : it->second)
+        if (M >= e.m_lo && M <= e.m_hi) { *out = e; return true; }
+    return false;
+}
 
 static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = false, bool rope = false, bool w8a8 = false) {
     Plan pl;
@@ -92,9 +116,16 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
             pick = -1;
         }
     }
+    // a measured plan for this shape, if the table holds one (entries were checked when they were set)
+    int t_split = 0;
+    PlanEntry te;
+    if (plan_lookup((group ? QL_PLAN_GROUP : 0) | (silu ? QL_PLAN_SILU : 0) | (rope ? QL_PLAN_ROPE : 0) | (w8a8 ? QL_PLAN_W8A8 : 0),
+                    M, N, K, &te)) {
+        mt = te.mt; wn = te.wn; wk = te.wk; cp = te.cp; t_split = te.split;
+    }
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group) && !(silu && (f_wn & 1)) &&
         !(rope && !rope_tile_built(f_mt, f_wn, f_wk, f_cp))) {
-        mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
+        mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp; t_split = 0;
     }
     pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
     const int kb = 32 * cp * wk;
@@ -110,6 +141,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     if (base < 144) split = K >= 8192 ? (K + 2047) / 2048 : (K + 1023) / 1024;
     else if (base < 160 && pick < nladder - 1) split = (K + 1023) / 1024;
     else if (base < 512 && K >= 4096) split = (K + 4095) / 4096;   // long K: at most four chunks per slice
+    if (t_split > 0) split = t_split;
     if (f_split > 0) split = f_split;
     if (silu) split = 1;                                    // gate and up meet in the epilogue of ONE workgroup
     if (split > 64) split = 64;
@@ -138,8 +170,13 @@ static Plan make_plan_partial(int64_t M, int64_t N, int64_t K, bool group) {
     int64_t cap = 512;
     if (base32 * kc > 256 && base64 * kc <= 256) { wn = 2; wk = 4; cp = 8; cap = 256; }
     if (M > 256) { mt = 2; wn = 2; wk = 4; cp = 8; cap = 256; }          // 64 x 64
+    int t_split = 0;
+    PlanEntry te;
+    if (plan_lookup(QL_PLAN_PARTIAL | (group ? QL_PLAN_GROUP : 0), M, N, K, &te)) {
+        mt = te.mt; wn = te.wn; wk = te.wk; cp = te.cp; t_split = te.split;   // (one slice: the caller does not defer)
+    }
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && tile_built(f_mt, f_wn, f_wk, f_cp, group)) {
-        mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;
+        mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp; t_split = 0;
     }
     pl.mt = mt; pl.wn = wn; pl.wk = wk; pl.cp = cp;
     const int kb = 32 * cp * wk;
@@ -150,6 +187,7 @@ static Plan make_plan_partial(int64_t M, int64_t N, int64_t K, bool group) {
     // two slices of a grid that already has a workgroup per CU gain less than the consumer's extra reads cost
     // (measured): report one slice, and the caller keeps the self-contained GEMM
     if (split == 2 && base32 * kc > 256) split = 1;
+    if (t_split > 0) split = t_split;
     if (f_split > 0) split = f_split;
     if (split > kchunks) split = kchunks;
     if (split > 16) split = 16;
@@ -223,10 +261,17 @@ extern "C" {
 
 size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
-    // (the qkv entry points with the RoPE epilogue may plan differently: cover both)
-    const size_t a = plan_workspace(make_plan(M, N, K, granularity == QL_PER_GROUP));
-    const size_t b = (N % 128 == 0) ? plan_workspace(make_plan(M, N, K, granularity == QL_PER_GROUP, false, true)) : 0;
-    return a > b ? a : b;
+    // (the qkv entry points with the RoPE epilogue may plan differently, and the W8A8 entry points may hold
+    // plan-table entries of their own: cover them all)
+    const bool grp = granularity == QL_PER_GROUP;
+    size_t need = plan_workspace(make_plan(M, N, K, grp));
+    const bool heads = N % 128 == 0;
+    if (heads) need = std::max(need, plan_workspace(make_plan(M, N, K, grp, false, true)));
+    if (!grp) {
+        need = std::max(need, plan_workspace(make_plan(M, N, K, false, false, false, true)));
+        if (heads) need = std::max(need, plan_workspace(make_plan(M, N, K, false, false, true, true)));
+    }
+    return need;
 }
 
 size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int granularity) {
@@ -254,6 +299,67 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
     f_wk = any ? wk : 0;
     f_cp = any ? cp : 0;
     f_split = split_k > 0 ? split_k : 0;
+    return QL_OK;
+}
+
+int ql_gemm_plan_set(int form, int64_t m_lo, int64_t m_hi, int64_t N, int64_t K, int mt, int wn, int wk, int cp, int split_k) {
+    const char* fn = "ql_gemm_plan_set";
+    const int known = QL_PLAN_GROUP | QL_PLAN_SILU | QL_PLAN_ROPE | QL_PLAN_W8A8 | QL_PLAN_PARTIAL;
+    const bool group = (form & QL_PLAN_GROUP) != 0, silu = (form & QL_PLAN_SILU) != 0, rope = (form & QL_PLAN_ROPE) != 0;
+    const bool partial = (form & QL_PLAN_PARTIAL) != 0;
+    if (form < 0 || (form & ~known) || (silu && rope) || (partial && (silu || rope)) || ((form & QL_PLAN_W8A8) && group) ||
+        m_lo < 1 || m_hi < m_lo || N <= 0 || K <= 0 || K % 32 || split_k < 1 || split_k > 64) {
+        set_error("%s: bad argument (form=%d rows %lld..%lld N=%lld K=%lld split=%d)", fn, form, (long long)m_lo,
+                  (long long)m_hi, (long long)N, (long long)K, split_k);
+        return QL_EINVAL;
+    }
+    if (!tile_built(mt, wn, wk, cp, group) || (silu && ((wn & 1) || split_k != 1)) || (rope && !rope_tile_built(mt, wn, wk, cp)) ||
+        (rope && N % 128)) {
+        set_error("%s: tile (mt=%d, wn=%d, wk=%d, cp=%d) with %d slices cannot run form %d", fn, mt, wn, wk, cp, split_k, form);
+        return QL_EINVAL;
+    }
+    // (the self-contained split-K keeps one ticket per output tile of the smallest row count the entry covers)
+    const int64_t tiles = ((m_hi + 32 * mt - 1) / (32 * mt)) * ((N + 32 * wn - 1) / (32 * wn));
+    if (!partial && split_k > 1 && tiles > kMaxTiles) {
+        set_error("%s: %lld output tiles exceed the %d split-K tickets", fn, (long long)tiles, kMaxTiles);
+        return QL_EINVAL;
+    }
+    if (partial && split_k > 16) { set_error("%s: the deferred form takes at most 16 slices", fn); return QL_EINVAL; }
+    std::unique_lock<std::shared_mutex> lock(g_plans_mu);
+    std::vector<PlanEntry>& v = g_plans[std::make_tuple(form, N, K)];
+    for (const PlanEntry& e : v)
+        if (m_lo <= e.m_hi && e.m_lo <= m_hi) {
+            set_error("%s: rows %lld..%lld overlap an entry of the same form and shape (%lld..%lld)", fn, (long long)m_lo,
+                      (long long)m_hi, (long long)e.m_lo, (long long)e.m_hi);
+            return QL_EINVAL;
+        }
+    v.push_back(PlanEntry{m_lo, m_hi, mt, wn, wk, cp, split_k});
+    return QL_OK;
+}
+
+void ql_gemm_plan_clear(void) {
+    std::unique_lock<std::shared_mutex> lock(g_plans_mu);
+    g_plans.clear();
+}
+
+int ql_gemm_plan_count(void) {
+    std::shared_lock<std::shared_mutex> lock(g_plans_mu);
+    int n = 0;
+    for (const auto& kv : g_plans) n += (int)kv.second.size();
+    return n;
+}
+
+int ql_gemm_plan_query(int form, int64_t M, int64_t N, int64_t K, int* out) {
+    const int known = QL_PLAN_GROUP | QL_PLAN_SILU | QL_PLAN_ROPE | QL_PLAN_W8A8 | QL_PLAN_PARTIAL;
+    if (!out || form < 0 || (form & ~known) || M <= 0 || N <= 0 || K <= 0 || K % 32) {
+        set_error("ql_gemm_plan_query: bad argument");
+        return QL_EINVAL;
+    }
+    const bool group = (form & QL_PLAN_GROUP) != 0;
+    const Plan pl = (form & QL_PLAN_PARTIAL) ? make_plan_partial(M, N, K, group)
+                                             : make_plan(M, N, K, group, (form & QL_PLAN_SILU) != 0, (form & QL_PLAN_ROPE) != 0,
+                                                         (form & QL_PLAN_W8A8) != 0);
+    out[0] = pl.mt; out[1] = pl.wn; out[2] = pl.wk; out[3] = pl.cp; out[4] = pl.split;
     return QL_OK;
 }
 

@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("QLINEAR_LIB") or os.path.join(_HERE, "_lib", "libqlin
 QL_INT8, QL_FP8 = 0, 1
 QL_TILED = 16
 QL_PER_ROW, QL_PER_TENSOR, QL_PER_GROUP = 0, 1, 2
+QL_PLAN_GROUP, QL_PLAN_SILU, QL_PLAN_ROPE, QL_PLAN_W8A8, QL_PLAN_PARTIAL = 1, 2, 4, 8, 16
+PLAN_TABLE = os.environ.get("QLINEAR_PLANS") or os.path.join(_HERE, "_plans", "gfx950.json")
 
 _c_vp, _c_i64, _c_int, _c_sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 
@@ -48,6 +50,10 @@ SIGNATURES = {
                                    _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int,
                                    _c_int, _c_vp, _c_sz, _c_vp]),
     "ql_gemm_force_config": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ql_gemm_plan_set": (_c_int, [_c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ql_gemm_plan_clear": (None, []),
+    "ql_gemm_plan_count": (_c_int, []),
+    "ql_gemm_plan_query": (_c_int, [_c_int, _c_i64, _c_i64, _c_i64, ctypes.POINTER(_c_int)]),
     "ql_add_rmsnorm": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_add_rmsnorm_quant": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     "ql_silu_mul": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
@@ -97,7 +103,37 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    if not os.environ.get("QLINEAR_NO_PLANS"):
+        load_plan_table(PLAN_TABLE)
     return lib
+
+
+def load_plan_table(path, replace=False):
+    """Register the measured GEMM plans of a JSON file written by tools/autotune_plans.py:
+    {"plans": [{"form", "N", "K", "m_lo", "m_hi", "tile": [mt, wn, wk, cp], "split"}, ...]}.  Returns the number
+    of entries set; a missing file is no error (the built-in heuristics then apply to every shape)."""
+    import json
+    lib = load()
+    if replace:
+        lib.ql_gemm_plan_clear()
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        doc = json.load(f)
+    n = 0
+    for e in doc.get("plans", []):
+        mt, wn, wk, cp = e["tile"]
+        check(lib.ql_gemm_plan_set(int(e["form"]), int(e["m_lo"]), int(e["m_hi"]), int(e["N"]), int(e["K"]), mt, wn, wk, cp,
+                                   int(e["split"])))
+        n += 1
+    return n
+
+
+def plan_query(form, M, N, K):
+    """(mt, wn, wk, cp, split) of the plan a GEMM call of this form and shape would run."""
+    out = (_c_int * 5)()
+    check(load().ql_gemm_plan_query(form, M, N, K, out))
+    return tuple(out)
 
 
 def check(rc):
