@@ -51,6 +51,8 @@ struct GemmParams {
                                  // sums row-major and the NEXT launch (ql_add_rmsnorm_partial) adds the slices up
     int M, N, K;
     int group;                   // group size (per-group only)
+    unsigned gmagic;             // ceil(2^32 / (group / 32)): k / group = umulhi(k >> 5, gmagic) for every k < 2^31 the
+                                 // kernels see (0 when group / 32 is 1: the quotient is k >> 5 itself)
     int sw_stride;               // 1 per-row, 0 per-tensor
     int k_per_split;             // multiple of the block's K chunk
     int bias_after_round;        // 1: bf16(bf16(v) + b)   0: bf16(v + b)
@@ -177,7 +179,21 @@ void qgemm_kernel(const GemmParams p) {
     using FalseT = std::integral_constant<bool, false>;
     constexpr int LDS_MAIN = (ROPE || AMAX) ? C::LDS_ROPE : C::LDS;
     constexpr int DQ_OFF = (LDS_MAIN + 15) & ~15;                // DYNQ: per-row {QMAX / max, max / QMAX} behind everything else
-    __shared__ __attribute__((aligned(128))) unsigned char smem[DYNQ ? DQ_OFF + 8 * C::BM : LDS_MAIN];   // base must be a multiple of 32 (address ^ 16 below)
+    // Per-group scales staged in LDS on the single-buffer tiles: the scales of a chunk's groups, [group in chunk]
+    // [tile column] f32, travel with the chunk's activation tile - requested with it, stored with it - so that folding
+    // a finished group costs an LDS read instead of a global load in the middle of the weight stream.  Those tiles keep
+    // a ring of up to eight weight loads in flight per lane, and the wait counter is positional: waiting for a scale
+    // requested at the fold also waits for every weight load requested before it, i.e. drains the ring at every group
+    // (measured on the Qwen3-4B shapes: -4..9 % with the scales staged).  The double-buffered tiles request a chunk's
+    // weights a whole chunk ahead, so the fold's load waits for nothing that has not landed; staged scales cost them
+    // 10 % (more LDS traffic between the fragment reads) and they keep the load.
+    constexpr bool SLDS = GROUP && !DB;
+    constexpr int SPC = C::KB / 32;                              // groups per chunk at most (group >= 32)
+    constexpr int SC_BYTES = SLDS ? C::BN * SPC * 4 : 0;         // per buffer
+    constexpr int SC_OFF = (LDS_MAIN + 15) & ~15;
+    constexpr int NSL = SLDS ? (C::BN * SPC + C::NT - 1) / C::NT : 1;   // scale loads per thread and chunk at most
+    static_assert(!SLDS || SC_OFF + (DB ? 2 : 1) * SC_BYTES <= 160 * 1024, "LDS budget with the staged group scales");
+    __shared__ __attribute__((aligned(128))) unsigned char smem[DYNQ ? DQ_OFF + 8 * C::BM : SLDS ? SC_OFF + (DB ? 2 : 1) * SC_BYTES : LDS_MAIN];   // base must be a multiple of 32 (address ^ 16 below)
 
     // The kernel is VALU-issue-bound at decode sizes, so everything that is uniform per wave is kept
     // in scalar registers (the wave index is made provably uniform) and every per-lane address is
@@ -364,11 +380,49 @@ void qgemm_kernel(const GemmParams p) {
             *(i32x4*)(smem + buf * C::XBYTES + lds_off<RB>(st_row0 + j * RS, st_ci)) = piece;
         }
     };
-    auto load_x = [&](auto chk, int kc) { load_x_to(chk, kc, sreg); };
-    auto store_x = [&](int buf) { store_x_from(buf, sreg); };
-    auto flush_group = [&](int kb) {
+    // group scales of the chunk at kc: thread t requests entries e = t + j * NT of [groups of the chunk][BN columns]
+    float screg[NSL];
+    // k / group without a division (an integer division costs ~30 instructions, and the main loop needs several per
+    // chunk): every k here is a multiple of 32, so the quotient is (k / 32) / (group / 32) by multiply-high
+    auto gdiv = [&](int k) -> int {
+        const unsigned q = (unsigned)k >> 5;
+        return p.gmagic ? (int)__umulhi(q, p.gmagic) : (int)q;
+    };
+    const int ngk = GROUP ? gdiv(p.K) : 1;                         // scales per weight row
+    int s_cnt = 0;                                                // entries of the chunk whose scales are in screg
+    auto load_s = [&](int kc) {
+        if constexpr (SLDS) {
+            const int g0 = gdiv(kc), cnt = C::BN * (gdiv(min(kc + C::KB, kend) - 32) - g0 + 1);
+            s_cnt = cnt;
+            const int nblk = (int)(bx * C::BN);
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                const int e = tid + j * C::NT;
+                const int col = min(nblk + (e % C::BN), p.N - 1);
+                if (e < cnt) screg[j] = p.sw[(size_t)col * ngk + g0 + e / C::BN];
+            }
+        }
+    };
+    auto store_s = [&](int buf, int kc) {
+        if constexpr (SLDS) {
+            const int cnt = s_cnt;                                // (the chunk load_s was last called for: kc)
+            float* dst = (float*)(smem + SC_OFF + buf * SC_BYTES);
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                const int e = tid + j * C::NT;
+                if (e < cnt) dst[e] = screg[j];
+            }
+        }
+    };
+    auto load_x = [&](auto chk, int kc) { load_x_to(chk, kc, sreg); load_s(kc); };
+    auto store_x = [&](int buf, int kc) { store_x_from(buf, sreg); store_s(buf, kc); };
+    auto flush_group = [&](int kb, int kc, int buf) {
         // fold the finished group's partial sums into the running sum with the group's f32 scale
-        const float s = p.sw[(size_t)nrow * (p.K / p.group) + kb / p.group];
+        float s;
+        if constexpr (SLDS)
+            s = ((const float*)(smem + SC_OFF + buf * SC_BYTES))[(gdiv(kb) - gdiv(kc)) * C::BN + wn * 32 + l31];
+        else
+            s = p.sw[(size_t)nrow * ngk + gdiv(kb)];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -428,7 +482,7 @@ void qgemm_kernel(const GemmParams p) {
             // starts at another k: it may belong to another group or continue this one, and both are handled
             // by scaling what has been summed so far with the current group's scale).  Any group size that is
             // a multiple of the 32-k step is exact this way, whatever its relation to the chunk length.
-            if (((kb + 32) % p.group) == 0 || c == CP - 1 || kb + 32 >= kend) flush_group(kb);
+            if (gdiv(kb + 32) * p.group == kb + 32 || c == CP - 1 || kb + 32 >= kend) flush_group(kb, kc, buf);
         }
     };
 
@@ -455,7 +509,7 @@ void qgemm_kernel(const GemmParams p) {
                 wcur[c] = load_w_ring(kc + C::KB, c);
                 step(chk, buf, kc, c, w);
             }
-            if (more) store_x(buf ^ 1);
+            if (more) store_x(buf ^ 1, kc + C::KB);
         } else {
             if (more) {
 #pragma unroll
@@ -465,7 +519,7 @@ void qgemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int c = 0; c < CP; ++c) step(chk, buf, kc, c, wcur[c]);
             if (more) {
-                store_x(buf ^ 1);
+                store_x(buf ^ 1, kc + C::KB);
 #pragma unroll
                 for (int c = 0; c < CP; ++c) wcur[c] = wnext[c];
             }
@@ -495,7 +549,7 @@ void qgemm_kernel(const GemmParams p) {
         load_x(chk, kc);
 #pragma unroll
         for (int j = 0; j < D; ++j) wcur[j] = load_w1(chk, kc, j);
-        store_x(0);
+        store_x(0, kc);
         __syncthreads();
         for (int c0 = 0; c0 < CP; c0 += D) {
 #pragma unroll
@@ -541,7 +595,7 @@ void qgemm_kernel(const GemmParams p) {
             load_x(TrueT{}, k0);                                  // (before the weights: positional wait counter)
 #pragma unroll
             for (int c = 0; c < CP; ++c) wcur[c] = load_w1(TrueT{}, k0, c);
-            store_x(0);
+            store_x(0, k0);
         }
         __syncthreads();
         // (whole chunks in a loop of ONE body, the ragged last chunk after it: with both variants inside the loop
