@@ -112,7 +112,8 @@ int ql_gemm_w8a16(int wdtype, int granularity, const void* x_bf16, const void* q
  * with QL_EWORKSPACE (ql_gemm_workspace_bytes tells in advance).  The array keeps the previous call's contents;
  * the call clears the ticket counters it will use (a small launch on `stream` in front of the GEMM).  All calls on one GPU share
  * the array: calls that overlap in time on one GPU (different streams, different threads) race.  The first call
- * on each device looks up the array's address; make it outside stream capture. */
+ * on each device looks up the array's address; make it outside stream capture.  The call plans with the built-in
+ * heuristics only (entries of the plan table, ql_gemm_plan_set, may split K further than the array holds). */
 #define QL_NOALLOC_SCRATCH_BYTES (16u << 20)
 int ql_gemm_w8a16_noalloc(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
                           const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,

@@ -48,7 +48,16 @@ struct PlanEntry { int64_t m_lo, m_hi; int mt, wn, wk, cp, split; };
 static std::map<std::tuple<int, int64_t, int64_t>, std::vector<PlanEntry>> g_plans;
 static std::shared_mutex g_plans_mu;
 
+// set while the allocation-free entry point plans a call: its fixed scratch array is sized for the heuristics' splits
+static thread_local bool tl_skip_table = false;
+struct SkipTable {
+    bool prev;
+    SkipTable() : prev(tl_skip_table) { tl_skip_table = true; }
+    ~SkipTable() { tl_skip_table = prev; }
+};
+
 static bool plan_lookup(int form, int64_t M, int64_t N, int64_t K, PlanEntry* out) {
+    if (tl_skip_table) return false;
     std::shared_lock<std::shared_mutex> lock(g_plans_mu);
     if (g_plans.empty()) return false;
     const auto it = g_plans.find(std::make_tuple(form, N, K));
@@ -465,9 +474,11 @@ namespace ql {
 int w8a16_dispatch(const char* fn, int wdtype, int granularity, const void* x, const void* qw, const float* sw,
                    const void* bias, void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace,
                    size_t workspace_bytes, void* stream) {
+    const SkipTable guard;
     return gemm_w8a16(fn, false, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, workspace, workspace_bytes, stream);
 }
 size_t w8a16_workspace_need(int64_t M, int64_t N, int64_t K, int granularity, size_t* ticket_bytes) {
+    const SkipTable guard;
     *ticket_bytes = 0;
     if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
     const Plan pl = make_plan(M, N, K, granularity == QL_PER_GROUP);
