@@ -292,14 +292,16 @@ int ql_lmhead_argmax(const void* x_bf16, const void* w_bf16, int64_t* tokens, fl
  * (nanovllm/layers/attention.py:64-69).  q [T,Hq,128], k/v [T,Hkv,128], out [T,Hq,128] bf16;
  * cu_seqlens int32 [num_seqs+1] in device memory, sequence s owns rows cu[s] .. cu[s+1]-1;
  * max_seqlen >= the longest sequence (sizes the grid).  out = softmax(scale * q k^T + causal) v with
- * f32 accumulation, probabilities rounded to bf16 before the second product.  Hq/Hkv in {1,2,4}. */
+ * f32 accumulation, probabilities rounded to bf16 before the second product.  Any Hq % Hkv == 0 (a kv head's query heads share
+ * a workgroup for the ratios 1, 2, 4; other ratios are dealt to workgroups of 4, 2 or 1 heads). */
 int ql_attn_prefill(const void* q, const void* k, const void* v, const int* cu_seqlens, void* out,
                     float scale, int num_seqs, int max_seqlen, int Hq, int Hkv, int head_dim, void* stream);
 
 /* Single-query attention over a paged KV cache: the decode half of Attention.forward
  * (nanovllm/layers/attention.py:59-75, flash_attn_with_kvcache there).  q/out [B,Hq,128];
  * caches [num_blocks, block_size, Hkv, 128]; block_tables [B, max_blocks]; context_lens [B]
- * (0 = padded row, output 0).  Hq/Hkv in {1,2,4}.  One workgroup per (sequence, kv head, 512-token
+ * (0 = padded row, output 0).  Any Hq % Hkv == 0 (ratios other than 1, 2, 4 re-read a kv head's K/V once per
+ * workgroup of 4, 2 or 1 query heads).  One workgroup per (sequence, kv head, 512-token
  * chunk); sequences longer than one chunk are merged by a second small launch through `workspace`
  * (ql_paged_attn_workspace_bytes bytes, no initialisation needed; calls sharing it must be
  * stream-ordered). */

@@ -34,13 +34,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const unsigned short*
                                                            const unsigned short* __restrict__ v,
                                                            const int* __restrict__ cu_seqlens,
                                                            unsigned short* __restrict__ out, float c_log2, int Hq,
-                                                           int Hkv) {
+                                                           int Hkv, int kv_group) {
     constexpr int SUBS = 4 / G;            // 32-row query blocks per head in this workgroup
     constexpr int QROWS = 32 * SUBS;
     __shared__ __attribute__((aligned(256))) unsigned char k_lds[kTileKeys * 256];
     __shared__ __attribute__((aligned(256))) unsigned char v_lds[kTileKeys * 256];
 
-    const int seq = blockIdx.z, hk = blockIdx.y;
+    // blockIdx.y counts groups of G query heads; a group reads the K/V of kv head (group * G) / kv_group, which is
+    // the group itself when a kv head's query heads form one group (kv_group == G: ratios 1, 2, 4); other ratios
+    // are dealt to several groups per kv head
+    const int seq = blockIdx.z, hgrp = blockIdx.y, hk = (hgrp * G) / kv_group;
     const int s0 = cu_seqlens[seq];
     const int L = cu_seqlens[seq + 1] - s0;
     const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QROWS;      // heaviest query blocks first
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const unsigned short*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave % G, sub = wave / G;
-    const int hq = hk * G + g;
+    const int hq = hgrp * G + g;
     const int l31 = lane & 31, hi = lane >> 5;
     const int qw0 = q0 + sub * 32;
     const int qrow = qw0 + l31;                                      // this lane's query (within the sequence)
@@ -209,17 +212,17 @@ extern "C" int ql_attn_prefill(const void* q, const void* k, const void* v, cons
         return QL_EINVAL;
     }
     if (head_dim != 128 || Hq % Hkv) { set_error("ql_attn_prefill: head_dim must be 128 and Hq %% Hkv == 0"); return QL_ESHAPE; }
-    const int G = Hq / Hkv;
-    if (G != 1 && G != 2 && G != 4) { set_error("ql_attn_prefill: Hq/Hkv=%d not built (1,2,4)", G); return QL_ESHAPE; }
+    const int kv_group = Hq / Hkv;
+    const int G = (kv_group % 4 == 0) ? 4 : (kv_group % 2 == 0) ? 2 : 1;     // query heads per workgroup
     if (num_seqs == 0 || max_seqlen == 0) return QL_OK;
-    if (num_seqs > 65535 || Hkv > 65535) { set_error("ql_attn_prefill: too many sequences or heads"); return QL_ESHAPE; }
+    if (num_seqs > 65535 || Hq / G > 65535) { set_error("ql_attn_prefill: too many sequences or heads"); return QL_ESHAPE; }
     const int qrows = 128 / G;
-    dim3 grid((unsigned)((max_seqlen + qrows - 1) / qrows), (unsigned)Hkv, (unsigned)num_seqs), block(256);
+    dim3 grid((unsigned)((max_seqlen + qrows - 1) / qrows), (unsigned)(Hq / G), (unsigned)num_seqs), block(256);
     const float c = scale * 1.4426950408889634f;
     hipStream_t s = as_stream(stream);
 #define QL_PF(G_)                                                                                              \
     hipLaunchKernelGGL(attn_prefill_kernel<G_>, grid, block, 0, s, (const unsigned short*)q, (const unsigned short*)k, \
-                       (const unsigned short*)v, cu_seqlens, (unsigned short*)out, c, Hq, Hkv)
+                       (const unsigned short*)v, cu_seqlens, (unsigned short*)out, c, Hq, Hkv, kv_group)
     if (G == 1) QL_PF(1); else if (G == 2) QL_PF(2); else QL_PF(4);
 #undef QL_PF
     QL_CHECK_LAUNCH("ql_attn_prefill");

@@ -236,7 +236,11 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const unsigned short* __restrict__ q, const unsigned short* __restrict__ k_cache,
     const unsigned short* __restrict__ v_cache, const int* __restrict__ block_tables,
     const int* __restrict__ context_lens, unsigned short* __restrict__ out, float scale, int Hq, int Hkv,
-    int block_size, int max_blocks, int max_chunks, float* __restrict__ partial, float* __restrict__ rowmax_out) {
+    int block_size, int max_blocks, int max_chunks, float* __restrict__ partial, float* __restrict__ rowmax_out,
+    int kv_heads, int kv_group) {
+    // Hkv / hk count GROUPS of G query heads that share one launch workgroup.  Normally a group is a kv head
+    // (kv_group == G, kv_heads == Hkv); for head ratios no kernel is built for (5, 8, ...) a kv head's query heads
+    // are dealt to several groups of 1, 2 or 4, each of which reads the K/V of kv head (hk * G) / kv_group.
     __shared__ float st_m[16][G], st_l[16][G];
     __shared__ float st_acc[16][G][128];
     const int b = blockIdx.x, hk = blockIdx.y, sp = blockIdx.z;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const int* bt = block_tables + (size_t)b * max_blocks;
     const int tbeg = sp * kAttnChunk;
     const int tend = min(ctx, tbeg + kAttnChunk);                 // tokens [tbeg, tend) of the sequence
-    const size_t hoff = (size_t)hk * 128 + seg * 8;
+    const size_t hoff = (size_t)((hk * G) / kv_group) * 128 + seg * 8;
     constexpr int U = QL_ATTN_U;   // tokens per slot per iteration: 2*U 16-byte loads in flight per lane
     // A chunk normally spans at most two cache blocks: their table entries are fetched once (uniform, so scalar
     // loads), which takes a dependent table load and an integer division out of every iteration.
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
             const int t = min(t0 + 16 * u, tend - 1);             // clamped: no divergent loads
             const size_t row = two ? (size_t)((t < bound ? base0 : base1) + t)
                                    : (size_t)bt[t / block_size] * block_size + (t % block_size);
-            const size_t off = row * Hkv * 128 + hoff;
+            const size_t off = row * kv_heads * 128 + hoff;
             // read-once stream: the non-temporal hint measured +5 % on the whole launch
             kk[u] = __builtin_nontemporal_load((const u16x8*)(k_cache + off));
             vv[u] = __builtin_nontemporal_load((const u16x8*)(v_cache + off));
@@ -632,8 +636,16 @@ static int paged_attn_decode(const void* q, const void* k_cache, const void* v_c
         return QL_EINVAL;
     }
     if (head_dim != 128 || Hq % Hkv) { set_error("ql_paged_attn_decode: head_dim must be 128 and Hq %% Hkv == 0"); return QL_ESHAPE; }
-    const int G = Hq / Hkv;
-    if (G != 1 && G != 2 && G != 4) { set_error("ql_paged_attn_decode: Hq/Hkv=%d not built (1,2,4)", G); return QL_ESHAPE; }
+    // query heads per workgroup: the whole kv head's group where a kernel is built for it (1, 2, 4), else the
+    // largest of those that divides it (8 -> two workgroups of 4 per kv head, 5 -> five of 1: K/V are then read
+    // once per workgroup, i.e. the ratio's quotient times)
+    const int kv_group = Hq / Hkv, kv_heads = Hkv;
+    const int G = (kv_group % 4 == 0) ? 4 : (kv_group % 2 == 0) ? 2 : 1;
+    if (G != kv_group && rowmax_out) {
+        set_error("ql_paged_attn_decode_rowmax: Hq/Hkv=%d (row maxima per kv head need 1, 2 or 4)", kv_group);
+        return QL_ESHAPE;
+    }
+    Hkv = Hq / G;                                    // from here on: groups of G query heads
     if (B == 0) return QL_OK;
     const size_t chunks = ((size_t)max_blocks * block_size + kAttnChunk - 1) / kAttnChunk;
     if (B > 0x7FFFFFFF || Hkv > 65535 || chunks > 65535) { set_error("ql_paged_attn_decode: batch too large"); return QL_ESHAPE; }
@@ -649,7 +661,7 @@ static int paged_attn_decode(const void* q, const void* k_cache, const void* v_c
         hipLaunchKernelGGL(paged_attn_decode_kernel<G_>, grid, block, 0, s, (const unsigned short*)q,               \
                            (const unsigned short*)k_cache, (const unsigned short*)v_cache, block_tables, context_lens, \
                            (unsigned short*)out, scale, Hq, Hkv, block_size, max_blocks, (int)chunks, (float*)workspace, \
-                           rowmax_out);                                                                             \
+                           rowmax_out, kv_heads, kv_group);                                                         \
         if (qdt == QL_INT8)                                                                                         \
             hipLaunchKernelGGL((paged_attn_finalize_quant_kernel<G_, QL_INT8>), dim3((unsigned)B), block, 0, s,     \
                                context_lens, (const float*)workspace, (unsigned short*)out, (unsigned char*)q_out,  \
