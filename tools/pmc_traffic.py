@@ -60,6 +60,10 @@ def kernel_fingerprint():
     h = hashlib.sha256()
     for f in ("ql_common.h", "ql_rope.h", "ql_gemm_kernel.h", "ql_gemm.hip"):
         h.update(open(os.path.join(root, f), "rb").read())
+    # ... and the measured plans the dispatch consults before its heuristics (which tile a launch runs)
+    plans = os.path.join(os.path.dirname(root), "nanovllm", "_plans", "gfx950.json")
+    if os.path.exists(plans):
+        h.update(open(plans, "rb").read())
     return h.hexdigest()
 
 
