@@ -416,19 +416,37 @@ void qgemm_kernel(const GemmParams p) {
     };
     auto load_x = [&](auto chk, int kc) { load_x_to(chk, kc, sreg); load_s(kc); };
     auto store_x = [&](int buf, int kc) { store_x_from(buf, sreg); store_s(buf, kc); };
-    auto flush_group = [&](int kb, int kc, int buf) {
+    // Double-buffered tiles: the scale of the group a wave is summing sits in a register, requested one fold ahead
+    // (at the fold before it, for the group of the wave's next step).  Requested at the fold itself, the load's wait
+    // drained every weight and activation request issued before it - on the prefill tiles the two chunks of
+    // operands they keep in flight - at every group end.
+    float s_ahead = 0.f;
+    if constexpr (GROUP && !SLDS) s_ahead = p.sw[(size_t)nrow * ngk + min(gdiv(min(k0 + wk * C::KW, p.K - 32)), ngk - 1)];
+    auto flush_group = [&](int kb, int kc, int buf, int c) {
         // fold the finished group's partial sums into the running sum with the group's f32 scale
         float s;
-        if constexpr (SLDS)
+        if constexpr (SLDS) {
             s = ((const float*)(smem + SC_OFF + buf * SC_BYTES))[(gdiv(kb) - gdiv(kc)) * C::BN + wn * 32 + l31];
-        else
-            s = p.sw[(size_t)nrow * ngk + gdiv(kb)];
+        } else {
+            s = s_ahead;
+            // the wave's next step: the next 32 k of its chunk part, or its part of the next chunk
+            const int kn = (c == CP - 1) ? kc + C::KB + wk * C::KW : kb + 32;
+            s_ahead = p.sw[(size_t)nrow * ngk + gdiv(min(kn, p.K - 32))];
+        }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 s2 = {s, s};
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][r] = __builtin_fmaf((float)accg[i][r], s, (float)acc[i][r]);
+            for (int r = 0; r < 16; r += 2) {
+                // (two accumulator registers per instruction: v_pk_fma_f32, the same fused arithmetic per element)
+                const f32x2 g2 = {(float)accg[i][r], (float)accg[i][r + 1]};
+                const f32x2 a2 = {(float)acc[i][r], (float)acc[i][r + 1]};
+                const f32x2 o2 = __builtin_elementwise_fma(g2, s2, a2);
+                acc[i][r] = o2[0];
+                acc[i][r + 1] = o2[1];
                 accg[i][r] = 0;
+                accg[i][r + 1] = 0;
             }
     };
     // one 32-k step of this wave: widen the 16 weight bytes of the lane, MT x (A fragment reads + MFMAs)
@@ -482,7 +500,7 @@ void qgemm_kernel(const GemmParams p) {
             // starts at another k: it may belong to another group or continue this one, and both are handled
             // by scaling what has been summed so far with the current group's scale).  Any group size that is
             // a multiple of the 32-k step is exact this way, whatever its relation to the chunk length.
-            if (gdiv(kb + 32) * p.group == kb + 32 || c == CP - 1 || kb + 32 >= kend) flush_group(kb, kc, buf);
+            if (gdiv(kb + 32) * p.group == kb + 32 || c == CP - 1 || kb + 32 >= kend) flush_group(kb, kc, buf, c);
         }
     };
 
