@@ -52,7 +52,7 @@ def ranges(ms):
 
 def make_mod(N, K, mode, dt, silu=False):
     w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
-    m = NQ.QGroupLinear(dt, w, None, 128) if mode == "group" else NQ.QLinear(dt, w, None, weight_only=True)
+    m = NQ.QGroupLinear(dt, w, None, 128) if mode == "group" else NQ.QLinear(dt, w, None, weight_only=(mode != "w8a8"))
     if silu:
         m.enable_silu_mul()
     return m.tile()
@@ -86,7 +86,8 @@ def tune_one(lib, fn, n_copies, cands, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="4b", choices=sorted(MODELS))
-    ap.add_argument("--mode", default="row", choices=["row", "group"])
+    ap.add_argument("--mode", default="row", choices=["row", "group", "w8a8"],
+                    help="row / group: W8A16 with per-row / g128 scales; w8a8: per-row W8A8 (quantized activations in)")
     ap.add_argument("--dtype", default="int8", choices=["int8", "fp8"])
     ap.add_argument("--ms", default=",".join(map(str, MS)))
     ap.add_argument("--forms", default="rope,silu,plain,partial")
@@ -100,9 +101,17 @@ def main():
     Q.workspace.reserve("cuda", 512 << 20)
     dt = torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn
     Hq, Hkv, H, I = MODELS[args.model]
-    gbit = Q.QL_PLAN_GROUP if args.mode == "group" else 0
+    gbit = {"row": 0, "group": Q.QL_PLAN_GROUP, "w8a8": Q.QL_PLAN_W8A8}[args.mode]
+    w8a8 = args.mode == "w8a8"
     ms = [int(v) for v in args.ms.split(",")]
     forms = args.forms.split(",")
+    if w8a8:
+        forms = [f for f in forms if f != "partial"]     # (the deferred W8A8 form shares the W8A16 entries)
+
+    def act(M, K):
+        """The activation operand of a launch: bf16 rows, or (qx, sx) for the W8A8 kernels."""
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        return NQ.per_row_quant(x, dt) if w8a8 else x
     plans, log = [], []
     t_start = time.time()
 
@@ -133,11 +142,14 @@ def main():
         kc = torch.zeros(64, 256, Hkv, 128, device="cuda", dtype=torch.bfloat16)
         vc = torch.zeros_like(kc)
         for M, lo, hi in ranges(ms):
-            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            x = act(M, K)
             pos = torch.randint(0, 2000, (M,), device="cuda")
             rows = cs.index_select(0, pos)
             slots = torch.randperm(64 * 256, device="cuda")[:M].to(torch.int32)
-            fn = lambda i: NQ.qkv_rope_matmul(mods[i], x, None, rows, nw, nw, 1e-6, Hq, Hkv, 128, kc, vc, slots, False)  # noqa: E731
+            if w8a8:
+                fn = lambda i: NQ.qkv_rope_matmul(mods[i], None, None, rows, nw, nw, 1e-6, Hq, Hkv, 128, kc, vc, slots, False, quantized=x)  # noqa: E731
+            else:
+                fn = lambda i: NQ.qkv_rope_matmul(mods[i], x, None, rows, nw, nw, 1e-6, Hq, Hkv, 128, kc, vc, slots, False)  # noqa: E731
             cands = [None] + [(t, s) for t in ROPE_TILES for s in (1, 2, 4) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and s <= max(1, K // (32 * t[3] * t[2]))]
             res, top = tune_one(lib, fn, nc, cands, args.iters)
@@ -150,8 +162,8 @@ def main():
         nc = min(copies(N, K), 40)
         mods = [make_mod(N, K, args.mode, dt, silu=True) for _ in range(nc)]
         for M, lo, hi in ranges(ms):
-            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
-            fn = lambda i: mods[i](x)  # noqa: E731
+            x = act(M, K)
+            fn = (lambda i: mods[i].forward_quantized(*x)) if w8a8 else (lambda i: mods[i](x))  # noqa: E731
             cands = [None] + [(t, 1) for t in TILES if t[1] % 2 == 0 and not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and not (args.mode == "group" and t[0] == 8)]
             res, top = tune_one(lib, fn, nc, cands, args.iters)
@@ -166,9 +178,12 @@ def main():
         mods = [make_mod(N, K, args.mode, dt) for _ in range(nc)]
         nw = torch.ones(N, device="cuda", dtype=torch.bfloat16)
         for M, lo, hi in ranges(ms):
-            x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            x = act(M, K)
             resid = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
-            plain_fn = lambda i: ops.add_rmsnorm(mods[i](x), resid, nw, 1e-6)  # noqa: E731
+            if w8a8:
+                plain_fn = lambda i: ops.add_rmsnorm(mods[i].forward_quantized(*x), resid, nw, 1e-6)  # noqa: E731
+            else:
+                plain_fn = lambda i: ops.add_rmsnorm(mods[i](x), resid, nw, 1e-6)  # noqa: E731
             cands = [None] + [(t, s) for t in TILES for s in (1, 2, 4, 8) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and not (args.mode == "group" and t[0] == 8) and s <= max(1, K // (32 * t[3] * t[2]))]
             res, top = tune_one(lib, plain_fn, nc, cands, args.iters)
@@ -212,7 +227,7 @@ def main():
             doc = json.load(open(args.out))
         mine = {(p["form"], p["N"], p["K"]) for p in plans} | {
             (f, n, k) for f in range(32) for (n, k) in [((Hq + 2 * Hkv) * 128, H), (2 * I, H), (H, Hq * 128), (H, I)]
-            if (f & Q.QL_PLAN_GROUP) == gbit}
+            if (f & (Q.QL_PLAN_GROUP | Q.QL_PLAN_W8A8)) == gbit}
         doc["plans"] = [p for p in doc.get("plans", []) if (p["form"], p["N"], p["K"]) not in mine] + plans
         doc["device"] = torch.cuda.get_device_name(0)
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
