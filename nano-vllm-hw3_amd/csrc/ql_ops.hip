@@ -256,12 +256,19 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     if (sp >= nsp) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = lane >> 4, seg = lane & 15;
-    float qv[G][8], acc[G][8], m[G], l[G];
+    // The arithmetic per cached token is what bounds this kernel once a kv head serves four query heads, so it is
+    // written on pairs: q . k as four bf16 dot-product instructions on the operands as they lie in memory (products
+    // exact, f32 sums; the softmax scale is applied to the finished dot product), the reduction over the 16 lanes of
+    // a token by row rotations inside the adds (no LDS traffic), and the output update as packed f32 operations.
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    int qp[G][4];                 // packed bf16 pairs of q, as loaded
+    f32x2_t acc[G][4];
+    float m[G], l[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const u16x8 a = *(const u16x8*)(q + ((size_t)b * Hq + hk * G + g) * 128 + seg * 8);
+        const i32x4 a = *(const i32x4*)(q + ((size_t)b * Hq + hk * G + g) * 128 + seg * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { qv[g][j] = bf16_bits_to_f32(a[j]) * scale; acc[g][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { qp[g][j] = a[j]; acc[g][j] = f32x2_t{0.f, 0.f}; }
         m[g] = -1e30f;
         l[g] = 0.f;
     }
@@ -293,20 +300,69 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (t0 + 16 * u < tend) {
-                float kf[8], vf[8];
+                const i32x4 kd = __builtin_bit_cast(i32x4, kk[u]), vd = __builtin_bit_cast(i32x4, vv[u]);
+                f32x2_t vf[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { kf[j] = bf16_bits_to_f32(kk[u][j]); vf[j] = bf16_bits_to_f32(vv[u][j]); }
+                for (int j = 0; j < 4; ++j)
+                    vf[j] = f32x2_t{__builtin_bit_cast(float, (unsigned)vd[j] << 16), __builtin_bit_cast(float, (unsigned)vd[j] & 0xFFFF0000u)};
+                // q . k for the G heads: bf16 dot-product instructions written inline, all heads in ONE statement so
+                // that their order is fixed (the compiler's selection of the builtin reused one operand pair for all
+                // four).  The compiler does not know these are dot instructions, whose result needs up to four wait
+                // states before another instruction may read or overwrite it: every head but the last has the later
+                // heads' four instructions behind it, the last one gets an explicit wait tied to its result.
+                float sc[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) sc[g] = 0.f;
+                static_assert(G == 1 || G == 2 || G == 4, "head groups of 1, 2 or 4");
+                if constexpr (G == 1) {
+                    asm("s_nop 0\n\tv_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %6\n\t"
+                        "v_dot2c_f32_bf16 %0, %3, %7\n\tv_dot2c_f32_bf16 %0, %4, %8"
+                        : "+v"(sc[0])
+                        : "v"(qp[0][0]), "v"(qp[0][1]), "v"(qp[0][2]), "v"(qp[0][3]), "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
+                } else if constexpr (G == 2) {
+                    asm("s_nop 0\n\t"
+                        "v_dot2c_f32_bf16 %0, %2, %10\n\tv_dot2c_f32_bf16 %0, %3, %11\n\t"
+                        "v_dot2c_f32_bf16 %0, %4, %12\n\tv_dot2c_f32_bf16 %0, %5, %13\n\t"
+                        "v_dot2c_f32_bf16 %1, %6, %10\n\tv_dot2c_f32_bf16 %1, %7, %11\n\t"
+                        "v_dot2c_f32_bf16 %1, %8, %12\n\tv_dot2c_f32_bf16 %1, %9, %13"
+                        : "+v"(sc[0]), "+v"(sc[G > 1 ? 1 : 0])
+                        : "v"(qp[0][0]), "v"(qp[0][1]), "v"(qp[0][2]), "v"(qp[0][3]),
+                          "v"(qp[G > 1 ? 1 : 0][0]), "v"(qp[G > 1 ? 1 : 0][1]), "v"(qp[G > 1 ? 1 : 0][2]), "v"(qp[G > 1 ? 1 : 0][3]),
+                          "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
+                } else {
+                    constexpr int g1 = G > 1 ? 1 : 0, g2 = G > 2 ? 2 : 0, g3 = G > 3 ? 3 : 0;
+                    asm("s_nop 0\n\t"
+                        "v_dot2c_f32_bf16 %0, %4, %20\n\tv_dot2c_f32_bf16 %0, %5, %21\n\t"
+                        "v_dot2c_f32_bf16 %0, %6, %22\n\tv_dot2c_f32_bf16 %0, %7, %23\n\t"
+                        "v_dot2c_f32_bf16 %1, %8, %20\n\tv_dot2c_f32_bf16 %1, %9, %21\n\t"
+                        "v_dot2c_f32_bf16 %1, %10, %22\n\tv_dot2c_f32_bf16 %1, %11, %23\n\t"
+                        "v_dot2c_f32_bf16 %2, %12, %20\n\tv_dot2c_f32_bf16 %2, %13, %21\n\t"
+                        "v_dot2c_f32_bf16 %2, %14, %22\n\tv_dot2c_f32_bf16 %2, %15, %23\n\t"
+                        "v_dot2c_f32_bf16 %3, %16, %20\n\tv_dot2c_f32_bf16 %3, %17, %21\n\t"
+                        "v_dot2c_f32_bf16 %3, %18, %22\n\tv_dot2c_f32_bf16 %3, %19, %23"
+                        : "+v"(sc[0]), "+v"(sc[g1]), "+v"(sc[g2]), "+v"(sc[g3])
+                        : "v"(qp[0][0]), "v"(qp[0][1]), "v"(qp[0][2]), "v"(qp[0][3]),
+                          "v"(qp[g1][0]), "v"(qp[g1][1]), "v"(qp[g1][2]), "v"(qp[g1][3]),
+                          "v"(qp[g2][0]), "v"(qp[g2][1]), "v"(qp[g2][2]), "v"(qp[g2][3]),
+                          "v"(qp[g3][0]), "v"(qp[g3][1]), "v"(qp[g3][2]), "v"(qp[g3][3]),
+                          "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
+                }
+                asm volatile("s_nop 3" : "+v"(sc[G - 1]));
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s += qv[g][j] * kf[j];
-                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                    float s = sc[g];
+                    // sum over the token's 16 lanes (one DPP row): rotations by 8, 4, 2, 1 leave the total in every lane
+                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, false));
+                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xF, 0xF, false));
+                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xF, 0xF, false));
+                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xF, 0xF, false));
+                    s *= scale;
                     const float mn = fmaxf(m[g], s);
                     const float alpha = __expf(m[g] - mn), pe = __expf(s - mn);
                     l[g] = l[g] * alpha + pe;
+                    const f32x2_t a2 = {alpha, alpha}, p2 = {pe, pe};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[g][j] = acc[g][j] * alpha + pe * vf[j];
+                    for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_elementwise_fma(p2, vf[j], acc[g][j] * a2);
                     m[g] = mn;
                 }
             }
@@ -317,7 +373,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     for (int g = 0; g < G; ++g) {
         if (seg == 0) { st_m[sidx][g] = m[g]; st_l[sidx][g] = l[g]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st_acc[sidx][g][seg * 8 + j] = acc[g][j];
+        for (int j = 0; j < 8; ++j) st_acc[sidx][g][seg * 8 + j] = acc[g][j >> 1][j & 1];
     }
     __syncthreads();
     const size_t tile = (size_t)b * Hkv + hk;
