@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
         m[g] = -1e30f;
         l[g] = 0.f;
     }
+    const float scale_log2 = scale * 1.4426950408889634f;
     const int* bt = block_tables + (size_t)b * max_blocks;
     const int tbeg = sp * kAttnChunk;
     const int tend = min(ctx, tbeg + kAttnChunk);                 // tokens [tbeg, tend) of the sequence
@@ -297,77 +298,78 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
             kk[u] = __builtin_nontemporal_load((const u16x8*)(k_cache + off));
             vv[u] = __builtin_nontemporal_load((const u16x8*)(v_cache + off));
         }
+        // ---- scores of the U tokens of this slot for the G heads
+        // q . k: bf16 dot-product instructions written inline (the compiler's selection of the builtin reused one
+        // operand pair for all four of a head).  The compiler does not know these are dot instructions, whose result
+        // needs up to four wait states before another instruction may read or overwrite it, so the statements are
+        // kept in order (volatile) and every result passes through a final wait statement.
+        float sc[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (t0 + 16 * u < tend) {
-                const i32x4 kd = __builtin_bit_cast(i32x4, kk[u]), vd = __builtin_bit_cast(i32x4, vv[u]);
-                f32x2_t vf[4];
+            const i32x4 kd = __builtin_bit_cast(i32x4, kk[u]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    vf[j] = f32x2_t{__builtin_bit_cast(float, (unsigned)vd[j] << 16), __builtin_bit_cast(float, (unsigned)vd[j] & 0xFFFF0000u)};
-                // q . k for the G heads: bf16 dot-product instructions written inline, all heads in ONE statement so
-                // that their order is fixed (the compiler's selection of the builtin reused one operand pair for all
-                // four).  The compiler does not know these are dot instructions, whose result needs up to four wait
-                // states before another instruction may read or overwrite it: every head but the last has the later
-                // heads' four instructions behind it, the last one gets an explicit wait tied to its result.
-                float sc[G];
+            for (int g = 0; g < G; ++g) {
+                sc[u][g] = 0.f;
+                asm volatile("s_nop 0\n\tv_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %6\n\t"
+                             "v_dot2c_f32_bf16 %0, %3, %7\n\tv_dot2c_f32_bf16 %0, %4, %8"
+                             : "+v"(sc[u][g])
+                             : "v"(qp[g][0]), "v"(qp[g][1]), "v"(qp[g][2]), "v"(qp[g][3]), "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
+            }
+        }
+        static_assert(U == 4 && (G == 1 || G == 2 || G == 4), "the wait statement below lists U x G results");
+        if constexpr (G == 1)
+            asm volatile("s_nop 3" : "+v"(sc[0][0]), "+v"(sc[1][0]), "+v"(sc[2][0]), "+v"(sc[3][0]));
+        else if constexpr (G == 2)
+            asm volatile("s_nop 3" : "+v"(sc[0][0]), "+v"(sc[0][G > 1 ? 1 : 0]), "+v"(sc[1][0]), "+v"(sc[1][G > 1 ? 1 : 0]),
+                                     "+v"(sc[2][0]), "+v"(sc[2][G > 1 ? 1 : 0]), "+v"(sc[3][0]), "+v"(sc[3][G > 1 ? 1 : 0]));
+        else
+            asm volatile("s_nop 3" : "+v"(sc[0][0]), "+v"(sc[0][G > 1 ? 1 : 0]), "+v"(sc[0][G > 2 ? 2 : 0]), "+v"(sc[0][G > 3 ? 3 : 0]),
+                                     "+v"(sc[1][0]), "+v"(sc[1][G > 1 ? 1 : 0]), "+v"(sc[1][G > 2 ? 2 : 0]), "+v"(sc[1][G > 3 ? 3 : 0]),
+                                     "+v"(sc[2][0]), "+v"(sc[2][G > 1 ? 1 : 0]), "+v"(sc[2][G > 2 ? 2 : 0]), "+v"(sc[2][G > 3 ? 3 : 0]),
+                                     "+v"(sc[3][0]), "+v"(sc[3][G > 1 ? 1 : 0]), "+v"(sc[3][G > 2 ? 2 : 0]), "+v"(sc[3][G > 3 ? 3 : 0]));
+        // ---- online softmax over the U tokens at once: one rescale of the running state per iteration
+        // (scores in log2 units: exp2 is the hardware's exponential; m is converted back when it leaves the loop)
 #pragma unroll
-                for (int g = 0; g < G; ++g) sc[g] = 0.f;
-                static_assert(G == 1 || G == 2 || G == 4, "head groups of 1, 2 or 4");
-                if constexpr (G == 1) {
-                    asm("s_nop 0\n\tv_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %6\n\t"
-                        "v_dot2c_f32_bf16 %0, %3, %7\n\tv_dot2c_f32_bf16 %0, %4, %8"
-                        : "+v"(sc[0])
-                        : "v"(qp[0][0]), "v"(qp[0][1]), "v"(qp[0][2]), "v"(qp[0][3]), "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
-                } else if constexpr (G == 2) {
-                    asm("s_nop 0\n\t"
-                        "v_dot2c_f32_bf16 %0, %2, %10\n\tv_dot2c_f32_bf16 %0, %3, %11\n\t"
-                        "v_dot2c_f32_bf16 %0, %4, %12\n\tv_dot2c_f32_bf16 %0, %5, %13\n\t"
-                        "v_dot2c_f32_bf16 %1, %6, %10\n\tv_dot2c_f32_bf16 %1, %7, %11\n\t"
-                        "v_dot2c_f32_bf16 %1, %8, %12\n\tv_dot2c_f32_bf16 %1, %9, %13"
-                        : "+v"(sc[0]), "+v"(sc[G > 1 ? 1 : 0])
-                        : "v"(qp[0][0]), "v"(qp[0][1]), "v"(qp[0][2]), "v"(qp[0][3]),
-                          "v"(qp[G > 1 ? 1 : 0][0]), "v"(qp[G > 1 ? 1 : 0][1]), "v"(qp[G > 1 ? 1 : 0][2]), "v"(qp[G > 1 ? 1 : 0][3]),
-                          "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
-                } else {
-                    constexpr int g1 = G > 1 ? 1 : 0, g2 = G > 2 ? 2 : 0, g3 = G > 3 ? 3 : 0;
-                    asm("s_nop 0\n\t"
-                        "v_dot2c_f32_bf16 %0, %4, %20\n\tv_dot2c_f32_bf16 %0, %5, %21\n\t"
-                        "v_dot2c_f32_bf16 %0, %6, %22\n\tv_dot2c_f32_bf16 %0, %7, %23\n\t"
-                        "v_dot2c_f32_bf16 %1, %8, %20\n\tv_dot2c_f32_bf16 %1, %9, %21\n\t"
-                        "v_dot2c_f32_bf16 %1, %10, %22\n\tv_dot2c_f32_bf16 %1, %11, %23\n\t"
-                        "v_dot2c_f32_bf16 %2, %12, %20\n\tv_dot2c_f32_bf16 %2, %13, %21\n\t"
-                        "v_dot2c_f32_bf16 %2, %14, %22\n\tv_dot2c_f32_bf16 %2, %15, %23\n\t"
-                        "v_dot2c_f32_bf16 %3, %16, %20\n\tv_dot2c_f32_bf16 %3, %17, %21\n\t"
-                        "v_dot2c_f32_bf16 %3, %18, %22\n\tv_dot2c_f32_bf16 %3, %19, %23"
-                        : "+v"(sc[0]), "+v"(sc[g1]), "+v"(sc[g2]), "+v"(sc[g3])
-                        : "v"(qp[0][0]), "v"(qp[0][1]), "v"(qp[0][2]), "v"(qp[0][3]),
-                          "v"(qp[g1][0]), "v"(qp[g1][1]), "v"(qp[g1][2]), "v"(qp[g1][3]),
-                          "v"(qp[g2][0]), "v"(qp[g2][1]), "v"(qp[g2][2]), "v"(qp[g2][3]),
-                          "v"(qp[g3][0]), "v"(qp[g3][1]), "v"(qp[g3][2]), "v"(qp[g3][3]),
-                          "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
-                }
-                asm volatile("s_nop 3" : "+v"(sc[G - 1]));
+        for (int g = 0; g < G; ++g) {
+            float sv[U], mn = m[g];
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    float s = sc[g];
-                    // sum over the token's 16 lanes (one DPP row): rotations by 8, 4, 2, 1 leave the total in every lane
-                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, false));
-                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xF, 0xF, false));
-                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xF, 0xF, false));
-                    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xF, 0xF, false));
-                    s *= scale;
-                    const float mn = fmaxf(m[g], s);
-                    const float alpha = __expf(m[g] - mn), pe = __expf(s - mn);
-                    l[g] = l[g] * alpha + pe;
-                    const f32x2_t a2 = {alpha, alpha}, p2 = {pe, pe};
+            for (int u = 0; u < U; ++u) {
+                float s = sc[u][g];
+                // sum over the token's 16 lanes (one DPP row): rotations by 8, 4, 2, 1 leave the total in every lane
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, false));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xF, 0xF, false));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xF, 0xF, false));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xF, 0xF, false));
+                sv[u] = (t0 + 16 * u < tend) ? s * scale_log2 : -1e30f;      // (tokens past the chunk: weight 0)
+                mn = fmaxf(mn, sv[u]);
+            }
+            const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
+            float pe[U], psum = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_elementwise_fma(p2, vf[j], acc[g][j] * a2);
-                    m[g] = mn;
-                }
+            for (int u = 0; u < U; ++u) { pe[u] = __builtin_amdgcn_exp2f(sv[u] - mn); psum += pe[u]; }
+            l[g] = l[g] * alpha + psum;
+            m[g] = mn;
+            const f32x2_t a2 = {alpha, alpha};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][j] = acc[g][j] * a2;
+#pragma unroll
+            for (int u = 0; u < U; ++u) sc[u][g] = pe[u];
+        }
+        // ---- output update: V of each token widened once, shared by the G heads
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const i32x4 vd = __builtin_bit_cast(i32x4, vv[u]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2_t vf = {__builtin_bit_cast(float, (unsigned)vd[j] << 16), __builtin_bit_cast(float, (unsigned)vd[j] & 0xFFFF0000u)};
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][j] = __builtin_elementwise_fma(f32x2_t{sc[u][g], sc[u][g]}, vf, acc[g][j]);
             }
         }
     }
+    // (the per-slot and per-chunk states below carry m in natural-log units)
+#pragma unroll
+    for (int g = 0; g < G; ++g) m[g] *= 0.6931471805599453f;
     const int sidx = wave * 4 + slot;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
