@@ -3,6 +3,7 @@
 // KV-cache store, SiLU*mul, and single-token (decode) attention over a paged KV cache.
 // All are HBM/L2-bound: 16-byte accesses per lane, f32 math, bf16 storage.
 #include "ql_common.h"
+#include <type_traits>
 #include "ql_rope.h"
 
 namespace ql {
@@ -230,6 +231,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(const unsigned s
 #ifndef QL_ATTN_U
 #define QL_ATTN_U 4
 #endif
+#ifndef QL_ATTN_LPT
+#define QL_ATTN_LPT 8
+#endif
 constexpr int kAttnChunk = QL_ATTN_CHUNK;
 template <int G>
 __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
@@ -255,20 +259,31 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     }
     if (sp >= nsp) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = lane >> 4, seg = lane & 15;
+    // LPT lanes share a cached token, each holding DPL = 128 / LPT of its dimensions.  Everything that is per token and
+    // head (the lane reduction of q . k, the softmax arithmetic) is repeated on all of a token's lanes, so fewer lanes
+    // per token mean less repeated work: 8 lanes x 16 dimensions (two 16-byte loads per tensor and token) instead
+    // of 16 x 8 cuts the vector instructions per token by a quarter.
+    constexpr int LPT = QL_ATTN_LPT, DPL = 128 / LPT, NP = DPL / 2, NL = DPL / 8, SPW = 64 / LPT;
+    static_assert(LPT == 8 || LPT == 16, "lanes per token");
+    const int slot = lane / LPT, seg = lane % LPT;
+    // the lane's h-th run of 8 dimensions: a token's lanes together read whole contiguous 16 * LPT bytes per load
+    auto dim0 = [&](int h) { return h * (8 * LPT) + seg * 8; };
     // The arithmetic per cached token is what bounds this kernel once a kv head serves four query heads, so it is
-    // written on pairs: q . k as four bf16 dot-product instructions on the operands as they lie in memory (products
-    // exact, f32 sums; the softmax scale is applied to the finished dot product), the reduction over the 16 lanes of
-    // a token by row rotations inside the adds (no LDS traffic), and the output update as packed f32 operations.
+    // written on pairs: q . k as bf16 dot-product instructions on the operands as they lie in memory (products
+    // exact, f32 sums; the softmax scale is applied to the finished dot product), the reduction over the lanes of
+    // a token by DPP permutes inside the adds (no LDS traffic), and the output update as packed f32 operations.
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    int qp[G][4];                 // packed bf16 pairs of q, as loaded
-    f32x2_t acc[G][4];
+    int qp[G][NP];                // packed bf16 pairs of q, as loaded
+    f32x2_t acc[G][NP];
     float m[G], l[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const i32x4 a = *(const i32x4*)(q + ((size_t)b * Hq + hk * G + g) * 128 + seg * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { qp[g][j] = a[j]; acc[g][j] = f32x2_t{0.f, 0.f}; }
+        for (int h = 0; h < NL; ++h) {
+            const i32x4 a = *(const i32x4*)(q + ((size_t)b * Hq + hk * G + g) * 128 + dim0(h));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qp[g][4 * h + j] = a[j]; acc[g][4 * h + j] = f32x2_t{0.f, 0.f}; }
+        }
         m[g] = -1e30f;
         l[g] = 0.f;
     }
@@ -276,8 +291,11 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const int* bt = block_tables + (size_t)b * max_blocks;
     const int tbeg = sp * kAttnChunk;
     const int tend = min(ctx, tbeg + kAttnChunk);                 // tokens [tbeg, tend) of the sequence
-    const size_t hoff = (size_t)((hk * G) / kv_group) * 128 + seg * 8;
-    constexpr int U = QL_ATTN_U;   // tokens per slot per iteration: 2*U 16-byte loads in flight per lane
+    const size_t hoff = (size_t)((hk * G) / kv_group) * 128;
+    // tokens per slot per iteration: 2 * NL * U 16-byte loads in flight per lane (four heads x 16 dimensions of state
+    // leave registers for two)
+    constexpr int U = (LPT == 8 && G == 4) ? QL_ATTN_U / 2 : QL_ATTN_U;
+    constexpr int TPI = 4 * SPW;   // tokens the workgroup's slots take per step of u
     // A chunk normally spans at most two cache blocks: their table entries are fetched once (uniform, so scalar
     // loads), which takes a dependent table load and an integer division out of every iteration.
     const int b0 = tbeg / block_size;
@@ -286,17 +304,37 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const int e0 = bt[b0], e1 = bt[min(b0 + 1, max_blocks - 1)];
     const int base0 = e0 * block_size - b0 * block_size;          // cache row of token t = base + t
     const int base1 = e1 * block_size - bound;
-    for (int t0 = tbeg + wave * 4 + slot; t0 < tend; t0 += 16 * U) {
-        u16x8 kk[U], vv[U];
+    // sum over a token's lanes, the total left in every one of them
+    auto lane_sum = [&](float s) -> float {
+        auto dpp = [](float v, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, false));
+        };
+        if constexpr (LPT == 16) {                                // one DPP row: rotations by 8, 4, 2, 1
+            s += dpp(s, std::integral_constant<int, 0x128>{});
+            s += dpp(s, std::integral_constant<int, 0x124>{});
+            s += dpp(s, std::integral_constant<int, 0x122>{});
+            s += dpp(s, std::integral_constant<int, 0x121>{});
+        } else {                                                  // half a row: lane ^ 1, lane ^ 2, then 7 - lane
+            s += dpp(s, std::integral_constant<int, 0xB1>{});     // quad_perm [1, 0, 3, 2]
+            s += dpp(s, std::integral_constant<int, 0x4E>{});     // quad_perm [2, 3, 0, 1]
+            s += dpp(s, std::integral_constant<int, 0x141>{});    // row_half_mirror
+        }
+        return s;
+    };
+    for (int t0 = tbeg + wave * SPW + slot; t0 < tend; t0 += TPI * U) {
+        i32x4 kk[U][NL], vv[U][NL];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = min(t0 + 16 * u, tend - 1);             // clamped: no divergent loads
+            const int t = min(t0 + TPI * u, tend - 1);            // clamped: no divergent loads
             const size_t row = two ? (size_t)((t < bound ? base0 : base1) + t)
                                    : (size_t)bt[t / block_size] * block_size + (t % block_size);
             const size_t off = row * kv_heads * 128 + hoff;
             // read-once stream: the non-temporal hint measured +5 % on the whole launch
-            kk[u] = __builtin_nontemporal_load((const u16x8*)(k_cache + off));
-            vv[u] = __builtin_nontemporal_load((const u16x8*)(v_cache + off));
+#pragma unroll
+            for (int h = 0; h < NL; ++h) {
+                kk[u][h] = __builtin_nontemporal_load((const i32x4*)(k_cache + off + dim0(h)));
+                vv[u][h] = __builtin_nontemporal_load((const i32x4*)(v_cache + off + dim0(h)));
+            }
         }
         // ---- scores of the U tokens of this slot for the G heads
         // q . k: bf16 dot-product instructions written inline (the compiler's selection of the builtin reused one
@@ -306,27 +344,25 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
         float sc[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const i32x4 kd = __builtin_bit_cast(i32x4, kk[u]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 sc[u][g] = 0.f;
-                asm volatile("s_nop 0\n\tv_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %6\n\t"
-                             "v_dot2c_f32_bf16 %0, %3, %7\n\tv_dot2c_f32_bf16 %0, %4, %8"
-                             : "+v"(sc[u][g])
-                             : "v"(qp[g][0]), "v"(qp[g][1]), "v"(qp[g][2]), "v"(qp[g][3]), "v"(kd[0]), "v"(kd[1]), "v"(kd[2]), "v"(kd[3]));
+#pragma unroll
+                for (int h = 0; h < NL; ++h)
+                    asm volatile("s_nop 0\n\tv_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %6\n\t"
+                                 "v_dot2c_f32_bf16 %0, %3, %7\n\tv_dot2c_f32_bf16 %0, %4, %8"
+                                 : "+v"(sc[u][g])
+                                 : "v"(qp[g][4 * h]), "v"(qp[g][4 * h + 1]), "v"(qp[g][4 * h + 2]), "v"(qp[g][4 * h + 3]),
+                                   "v"(kk[u][h][0]), "v"(kk[u][h][1]), "v"(kk[u][h][2]), "v"(kk[u][h][3]));
             }
         }
-        static_assert(U == 4 && (G == 1 || G == 2 || G == 4), "the wait statement below lists U x G results");
-        if constexpr (G == 1)
-            asm volatile("s_nop 3" : "+v"(sc[0][0]), "+v"(sc[1][0]), "+v"(sc[2][0]), "+v"(sc[3][0]));
-        else if constexpr (G == 2)
-            asm volatile("s_nop 3" : "+v"(sc[0][0]), "+v"(sc[0][G > 1 ? 1 : 0]), "+v"(sc[1][0]), "+v"(sc[1][G > 1 ? 1 : 0]),
-                                     "+v"(sc[2][0]), "+v"(sc[2][G > 1 ? 1 : 0]), "+v"(sc[3][0]), "+v"(sc[3][G > 1 ? 1 : 0]));
-        else
-            asm volatile("s_nop 3" : "+v"(sc[0][0]), "+v"(sc[0][G > 1 ? 1 : 0]), "+v"(sc[0][G > 2 ? 2 : 0]), "+v"(sc[0][G > 3 ? 3 : 0]),
-                                     "+v"(sc[1][0]), "+v"(sc[1][G > 1 ? 1 : 0]), "+v"(sc[1][G > 2 ? 2 : 0]), "+v"(sc[1][G > 3 ? 3 : 0]),
-                                     "+v"(sc[2][0]), "+v"(sc[2][G > 1 ? 1 : 0]), "+v"(sc[2][G > 2 ? 2 : 0]), "+v"(sc[2][G > 3 ? 3 : 0]),
-                                     "+v"(sc[3][0]), "+v"(sc[3][G > 1 ? 1 : 0]), "+v"(sc[3][G > 2 ? 2 : 0]), "+v"(sc[3][G > 3 ? 3 : 0]));
+        // (volatile statements keep their order: the wait follows the last dot block, and the empty statements, which
+        // every result passes through, follow the wait)
+        asm volatile("s_nop 3" : "+v"(sc[U - 1][G - 1]));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(sc[u][g]));
         // ---- online softmax over the U tokens at once: one rescale of the running state per iteration
         // (scores in log2 units: exp2 is the hardware's exponential; m is converted back when it leaves the loop)
 #pragma unroll
@@ -334,13 +370,8 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
             float sv[U], mn = m[g];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                float s = sc[u][g];
-                // sum over the token's 16 lanes (one DPP row): rotations by 8, 4, 2, 1 leave the total in every lane
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xF, 0xF, false));
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xF, 0xF, false));
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xF, 0xF, false));
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xF, 0xF, false));
-                sv[u] = (t0 + 16 * u < tend) ? s * scale_log2 : -1e30f;      // (tokens past the chunk: weight 0)
+                const float s = lane_sum(sc[u][g]);
+                sv[u] = (t0 + TPI * u < tend) ? s * scale_log2 : -1e30f;     // (tokens past the chunk: weight 0)
                 mn = fmaxf(mn, sv[u]);
             }
             const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
@@ -351,31 +382,53 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
             m[g] = mn;
             const f32x2_t a2 = {alpha, alpha};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[g][j] = acc[g][j] * a2;
+            for (int j = 0; j < NP; ++j) acc[g][j] = acc[g][j] * a2;
 #pragma unroll
             for (int u = 0; u < U; ++u) sc[u][g] = pe[u];
         }
         // ---- output update: V of each token widened once, shared by the G heads
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const i32x4 vd = __builtin_bit_cast(i32x4, vv[u]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x2_t vf = {__builtin_bit_cast(float, (unsigned)vd[j] << 16), __builtin_bit_cast(float, (unsigned)vd[j] & 0xFFFF0000u)};
+            for (int j = 0; j < NP; ++j) {
+                const unsigned vd = (unsigned)vv[u][j >> 2][j & 3];
+                const f32x2_t vf = {__builtin_bit_cast(float, vd << 16), __builtin_bit_cast(float, vd & 0xFFFF0000u)};
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g][j] = __builtin_elementwise_fma(f32x2_t{sc[u][g], sc[u][g]}, vf, acc[g][j]);
+            }
+        }
+    }
+    if constexpr (LPT == 8) {
+        // two slots share a 16-lane row: merge their states (lane ^ 8 holds the other slot's same dimensions), so that
+        // the workgroup hands 16 states to the reduction below, as with 16 lanes per token
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            auto other = [](float v) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+            };
+            const float mo = other(m[g]), lo = other(l[g]);
+            const float mn = fmaxf(m[g], mo);
+            const float wa = __builtin_amdgcn_exp2f(m[g] - mn), wb = __builtin_amdgcn_exp2f(mo - mn);
+            l[g] = l[g] * wa + lo * wb;
+            m[g] = mn;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const float o0 = other(acc[g][j][0]), o1 = other(acc[g][j][1]);
+                acc[g][j] = f32x2_t{acc[g][j][0] * wa + o0 * wb, acc[g][j][1] * wa + o1 * wb};
             }
         }
     }
     // (the per-slot and per-chunk states below carry m in natural-log units)
 #pragma unroll
     for (int g = 0; g < G; ++g) m[g] *= 0.6931471805599453f;
-    const int sidx = wave * 4 + slot;
+    const int sidx = wave * 4 + (lane >> 4);
+    if (LPT == 16 || (lane & 8) == 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (seg == 0) { st_m[sidx][g] = m[g]; st_l[sidx][g] = l[g]; }
+        for (int g = 0; g < G; ++g) {
+            if (seg == 0) { st_m[sidx][g] = m[g]; st_l[sidx][g] = l[g]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st_acc[sidx][g][seg * 8 + j] = acc[g][j >> 1][j & 1];
+            for (int j = 0; j < DPL; ++j) st_acc[sidx][g][dim0(j >> 3) + (j & 7)] = acc[g][j >> 1][j & 1];
+        }
     }
     __syncthreads();
     const size_t tile = (size_t)b * Hkv + hk;
