@@ -218,9 +218,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(const unsigned s
 // grid (batch, kv_head, chunk): one workgroup per chunk of CHUNK tokens of a sequence, so long and
 // short sequences load the chip evenly (a grid of one workgroup per sequence ends on its longest
 // sequence).  The G = Hq/Hkv query heads of a kv head share every K/V byte that is read.
-// A wave covers 4 tokens per step: lane = 16 * token_slot + dim_segment, one 16-byte (8 x bf16) load
-// of K and of V per lane and token, 4 tokens per slot in flight.  Online softmax per token slot; the
-// 16 slot states of the workgroup are merged through LDS.  A sequence with more than one chunk
+// A wave covers 8 tokens per step: lane = 8 * token_slot + dim_segment, two 16-byte (8 x bf16) loads
+// of K and of V per lane and token (dimensions [8 seg, 8 seg + 8) and 64 further on, so a token's lanes
+// read contiguous 128-byte runs), 4 tokens per slot in flight (2 with four heads per kv head).  Online
+// softmax over a slot's tokens in flight; slot pairs merge by a DPP exchange and the resulting 16 states
+// of the workgroup are merged through LDS.  A sequence with more than one chunk
 // stores its per-chunk (max, sum, weighted V) state and a second, tiny launch merges the chunks in
 // order.  (Merging in-kernel by the last chunk to arrive measured slower both ways: behind agent-scope
 // fences the L2 write-back / invalidate per chunk halves the stream rate, and with fence-free
