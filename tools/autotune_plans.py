@@ -39,11 +39,14 @@ ROPE_TILES = [(1, 4, 2, 16), (1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4)]
 PARTIAL_TILES = [(1, 1, 8, 4), (1, 1, 8, 8), (1, 2, 4, 8), (1, 2, 4, 4), (2, 2, 4, 8), (2, 2, 4, 4), (1, 4, 1, 4),
                  (1, 4, 2, 16), (2, 4, 1, 4), (2, 4, 2, 4), (1, 2, 4, 16)]
 MS = [16, 64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]
+PREFILL_MS = [1024, 2048, 4096, 8192, 16384]
+# prefill sizes: the double-buffered tiles of 64 rows and more, never split (thousands of tiles fill the chip)
+PREFILL_TILES = [(2, 4, 1, 4), (4, 4, 1, 4), (8, 4, 1, 4), (2, 4, 2, 4), (4, 4, 2, 4), (4, 8, 1, 2), (4, 8, 1, 4), (2, 2, 2, 4), (4, 2, 2, 4)]
+PREFILL_ROPE_TILES = [(2, 4, 1, 4), (2, 4, 2, 4), (4, 8, 1, 2), (4, 8, 1, 4)]
 MIN_GAIN = 0.03
 
 
-def ranges(ms):
-    lo = 1
+def ranges(ms, lo=1):
     for m in ms:
         hi = (m + 31) // 32 * 32
         yield m, lo, hi
@@ -89,7 +92,8 @@ def main():
     ap.add_argument("--mode", default="row", choices=["row", "group", "w8a8"],
                     help="row / group: W8A16 with per-row / g128 scales; w8a8: per-row W8A8 (quantized activations in)")
     ap.add_argument("--dtype", default="int8", choices=["int8", "fp8"])
-    ap.add_argument("--ms", default=",".join(map(str, MS)))
+    ap.add_argument("--ms", default="")
+    ap.add_argument("--prefill", action="store_true", help="tune the prefill row counts (513 ... 16384) instead of the decode ones")
     ap.add_argument("--forms", default="rope,silu,plain,partial")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--out", default="")
@@ -99,12 +103,15 @@ def main():
     lib = Q.load()
     lib.ql_gemm_plan_clear()
     Q.workspace.reserve("cuda", 512 << 20)
+    if args.prefill:
+        args.iters = min(args.iters, 8)
     dt = torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn
     Hq, Hkv, H, I = MODELS[args.model]
     gbit = {"row": 0, "group": Q.QL_PLAN_GROUP, "w8a8": Q.QL_PLAN_W8A8}[args.mode]
     w8a8 = args.mode == "w8a8"
-    ms = [int(v) for v in args.ms.split(",")]
-    forms = args.forms.split(",")
+    ms = [int(v) for v in args.ms.split(",")] if args.ms else (PREFILL_MS if args.prefill else MS)
+    first_row = 513 if args.prefill else 1
+    forms = [f for f in args.forms.split(",") if not (args.prefill and f == "partial")]
     if w8a8:
         forms = [f for f in forms if f != "partial"]     # (the deferred W8A8 form shares the W8A16 entries)
 
@@ -141,7 +148,7 @@ def main():
         nw = torch.ones(128, device="cuda", dtype=torch.bfloat16)
         kc = torch.zeros(64, 256, Hkv, 128, device="cuda", dtype=torch.bfloat16)
         vc = torch.zeros_like(kc)
-        for M, lo, hi in ranges(ms):
+        for M, lo, hi in ranges(ms, first_row):
             x = act(M, K)
             pos = torch.randint(0, 2000, (M,), device="cuda")
             rows = cs.index_select(0, pos)
@@ -152,6 +159,8 @@ def main():
                 fn = lambda i: NQ.qkv_rope_matmul(mods[i], x, None, rows, nw, nw, 1e-6, Hq, Hkv, 128, kc, vc, slots, False)  # noqa: E731
             cands = [None] + [(t, s) for t in ROPE_TILES for s in (1, 2, 4) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and s <= max(1, K // (32 * t[3] * t[2]))]
+            if args.prefill:
+                cands = [None] + [(t, 1) for t in PREFILL_ROPE_TILES]
             res, top = tune_one(lib, fn, nc, cands, args.iters)
             record(gbit | Q.QL_PLAN_ROPE, "qkv", N, K, M, lo, hi, res, top)
         del mods
@@ -161,10 +170,11 @@ def main():
         N, K = 2 * I, H
         nc = min(copies(N, K), 40)
         mods = [make_mod(N, K, args.mode, dt, silu=True) for _ in range(nc)]
-        for M, lo, hi in ranges(ms):
+        for M, lo, hi in ranges(ms, first_row):
             x = act(M, K)
             fn = (lambda i: mods[i].forward_quantized(*x)) if w8a8 else (lambda i: mods[i](x))  # noqa: E731
-            cands = [None] + [(t, 1) for t in TILES if t[1] % 2 == 0 and not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
+            cands = [None] + [(t, 1) for t in (PREFILL_TILES if args.prefill else TILES)
+                              if t[1] % 2 == 0 and not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and not (args.mode == "group" and t[0] == 8)]
             res, top = tune_one(lib, fn, nc, cands, args.iters)
             record(gbit | Q.QL_PLAN_SILU, "gate_up", N, K, M, lo, hi, res, top)
@@ -177,7 +187,7 @@ def main():
         nc = min(copies(N, K), 60)
         mods = [make_mod(N, K, args.mode, dt) for _ in range(nc)]
         nw = torch.ones(N, device="cuda", dtype=torch.bfloat16)
-        for M, lo, hi in ranges(ms):
+        for M, lo, hi in ranges(ms, first_row):
             x = act(M, K)
             resid = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
             if w8a8:
@@ -186,6 +196,8 @@ def main():
                 plain_fn = lambda i: ops.add_rmsnorm(mods[i](x), resid, nw, 1e-6)  # noqa: E731
             cands = [None] + [(t, s) for t in TILES for s in (1, 2, 4, 8) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and not (args.mode == "group" and t[0] == 8) and s <= max(1, K // (32 * t[3] * t[2]))]
+            if args.prefill:
+                cands = [None] + [(t, 1) for t in PREFILL_TILES if not (args.mode == "group" and t[0] == 8)]
             res, top = tune_one(lib, plain_fn, nc, cands, args.iters)
             if "plain" in forms:
                 record(gbit, name, N, K, M, lo, hi, res, top)
