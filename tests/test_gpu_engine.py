@@ -187,6 +187,38 @@ def test_paged_attn_decode_matches_torch(G):
     assert torch.equal(rm, out.view(B, Hkv, G * D).float().abs().amax(-1))
 
 
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_paged_attn_decode_lengths_around_the_kernel_steps(G):
+    """Context lengths on both sides of every boundary of the decode kernel's token walk: the 32 tokens a workgroup's
+    slots take per step, the 64 / 128 tokens of one loop iteration (two / four tokens per slot in flight), the 256-token
+    cache block and the 512-token chunk; block tables in scattered order."""
+    from nanovllm import ops
+    torch.manual_seed(11)
+    Hkv, D, bs = 2, 128, 256
+    Hq = Hkv * G
+    lens = [2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 254, 258, 383, 511, 512, 513, 640, 1023, 1024, 1025, 1500]
+    B = len(lens)
+    nblk = sum((l + bs - 1) // bs for l in lens) + 1
+    kc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    order = (torch.randperm(nblk - 1) + 1).tolist()
+    tables = torch.zeros(B, 8, dtype=torch.int32, device="cuda")
+    for b, l in enumerate(lens):
+        for j in range((l + bs - 1) // bs):
+            tables[b, j] = order.pop()
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.bfloat16)
+    ctx = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ops.reserve_attn_workspace(B, Hq, Hkv, bs, 8, "cuda")
+    out = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5)
+    for b, l in enumerate(lens):
+        idx = torch.cat([tables[b, j].long() * bs + torch.arange(bs, device="cuda") for j in range((l + bs - 1) // bs)])[:l]
+        k = kc.view(-1, Hkv, D)[idx].float().repeat_interleave(G, dim=1)
+        v = vc.view(-1, Hkv, D)[idx].float().repeat_interleave(G, dim=1)
+        s = torch.einsum("hd,lhd->hl", q[b].float(), k) * D ** -0.5
+        ref = torch.einsum("hl,lhd->hd", s.softmax(-1), v)
+        _close(out[b], ref, rtol=2 ** -6, atol=2e-2)
+
+
 @pytest.mark.parametrize("G", [1, 2, 4, 5, 8])
 def test_attn_prefill_varlen_matches_torch(G):
     """Packed causal self-attention against an fp32 softmax(QK^T)V per sequence; lengths straddle the
