@@ -11,9 +11,10 @@ random-initialised (no checkpoint on the box); data: synthetic.  With N > 1 the 
 parallel over N GPUs (one process per GPU, RCCL all-reduce in the row-parallel linears): the total
 work is fixed, so scaling is "strong".
 
-Rank 0 prints one JSON line with the metric, a `roofline` object for the dominant kernel (the decode
-W8A16 GEMM, HBM-bound: algorithmic bytes / launch duration measured with HIP events) and a
-`cpu_baseline` object (the reference's CPU arithmetic for the same linears, timed on host cores).
+Rank 0 prints one JSON line with the metric, a `roofline` object for the kernel of the hot path (the decode
+W8A16 GEMM, HBM-bound: algorithmic bytes / launch duration measured with HIP events), `roofline_prefill`
+(the same kernel at prefill size, MFMA-bound), `roofline_attention` (decode attention, the largest share of
+the bench's GPU time, HBM-bound) and a `cpu_baseline` object (the reference's CPU arithmetic for the same linears, timed on host cores).
 """
 import argparse
 import json
@@ -237,6 +238,47 @@ def measure_prefill_gemm(llm, M=16384):
             "traffic": None, "kernel": f"ql::qgemm_kernel (prefill W8A16 GEMM, four layer shapes, M = {M})"}
 
 
+def measure_decode_attention(llm):
+    """HBM-bound neighbour of the GEMMs, and the largest share of the bench's GPU time: the decode attention launch
+    (ql_paged_attn_decode + its merge launch) on a mid-run state of the workload - 131 running sequences (the mean
+    over the 1023 decode steps) with 300..1800 cached tokens each - over 8 distinct caches so that K/V stream from
+    HBM, captured into a hipGraph and timed with HIP events on the launch stream.  achieved = K/V bytes / time."""
+    from nanovllm import ops
+    hf = llm.model_runner.config.hf_config
+    Hq, Hkv, D, bs = hf.num_attention_heads, hf.num_key_value_heads, hf.head_dim, llm.model_runner.block_size
+    g = torch.Generator().manual_seed(0)
+    B, L = 131, 8
+    lens = torch.randint(300, 1800, (B,), generator=g)
+    nblk = int(((lens + bs - 1) // bs).sum()) + 1
+    with torch.inference_mode():
+        kc = [torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16) for _ in range(L)]
+        vc = [torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16) for _ in range(L)]
+        tables = torch.zeros(B, 16, dtype=torch.int32)
+        nxt = 1
+        for b in range(B):
+            for j in range((int(lens[b]) + bs - 1) // bs):
+                tables[b, j] = nxt
+                nxt += 1
+        tables = tables.cuda()
+        q = torch.randn(B, Hq, D, device="cuda", dtype=torch.bfloat16)
+        ctx = lens.to(torch.int32).cuda()
+        ops.reserve_attn_workspace(B, Hq, Hkv, bs, 16)
+
+        def run():
+            for _ in range(4):
+                for i in range(L):
+                    ops.paged_attn_decode(q, kc[i], vc[i], tables, ctx, D ** -0.5)
+        run()
+        torch.cuda.synchronize()
+        t = _graph_time(run, torch.cuda.Stream()) / (4 * L)
+    nbytes = float(lens.sum()) * Hkv * D * 2 * 2
+    gbps = nbytes / t / 1e9
+    return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+            "traffic": None, "kernel": "ql::paged_attn_decode_kernel + merge launch (131 sequences, 300..1800 cached tokens, "
+                                       f"{Hq} query / {Hkv} kv heads)",
+            "avg_launch_us": round(t * 1e6, 1), "avg_algorithmic_bytes": int(nbytes)}
+
+
 def cpu_baseline():
     """The reference's CPU-runnable forward arithmetic for the same linears (x.float() @ (qw.float()*sw).T,
     torch.matmul) on this box's host cores: all 112 quantized linears of one Qwen3-0.6B decode step at
@@ -369,13 +411,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    roof = roof_prefill = None
+    roof = roof_prefill = roof_attn = None
     # (one GPU only: under tensor parallelism the row-parallel modules' forward contains a collective, which one
     # rank must not issue alone)
     model_name = MODELS[args.model][0]
     if rank == 0 and world == 1 and not args.no_roofline and args.quant != "bf16" and args.model == "0.6b":
         roof = measure_decode_gemm(llm, step_batches[: len(step_batches) // max(args.steps, 1)])
         roof_prefill = measure_prefill_gemm(llm)
+        roof_attn = measure_decode_attention(llm)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -390,7 +433,7 @@ def main():
                                    f"(133,966 output tokens), {model_name} random-init, "
                                    f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, {decode_mode}",
                        "parallelism": f"tp{world}", "decode_steps": len(step_batches) // max(args.steps, 1)},
-            "roofline": roof, "roofline_prefill": roof_prefill, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_prefill": roof_prefill, "roofline_attention": roof_attn, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
