@@ -108,11 +108,14 @@ def load():
     return lib
 
 
-def load_plan_table(path, replace=False):
+def load_plan_table(path, replace=False, strict=False):
     """Register the measured GEMM plans of a JSON file written by tools/autotune_plans.py:
     {"plans": [{"form", "N", "K", "m_lo", "m_hi", "tile": [mt, wn, wk, cp], "split"}, ...]}.  Returns the number
-    of entries set; a missing file is no error (the built-in heuristics then apply to every shape)."""
+    of entries set; a missing file is no error (the built-in heuristics then apply to every shape).  An entry the
+    library rejects (a tile this build does not have, an overlap) is skipped with a warning - a plan is an
+    optimisation, never a reason not to start - unless ``strict``."""
     import json
+    import warnings
     lib = load()
     if replace:
         lib.ql_gemm_plan_clear()
@@ -123,8 +126,13 @@ def load_plan_table(path, replace=False):
     n = 0
     for e in doc.get("plans", []):
         mt, wn, wk, cp = e["tile"]
-        check(lib.ql_gemm_plan_set(int(e["form"]), int(e["m_lo"]), int(e["m_hi"]), int(e["N"]), int(e["K"]), mt, wn, wk, cp,
-                                   int(e["split"])))
+        rc = lib.ql_gemm_plan_set(int(e["form"]), int(e["m_lo"]), int(e["m_hi"]), int(e["N"]), int(e["K"]), mt, wn, wk, cp,
+                                  int(e["split"]))
+        if rc != 0:
+            if strict:
+                check(rc)
+            warnings.warn(f"{path}: plan entry skipped ({lib.ql_last_error().decode()})")
+            continue
         n += 1
     return n
 

@@ -86,6 +86,13 @@ def test_table_file_round_trip(lib, tmp_path):
     assert Q.plan_query(Q.QL_PLAN_GROUP | Q.QL_PLAN_PARTIAL, 64, 2560, 9728)[:4] == (1, 2, 4, 8)
     assert Q.load_plan_table(str(tmp_path / "missing.json"), replace=True) == 0
     assert lib.ql_gemm_plan_count() == 0
+    # an entry this build cannot run is skipped with a warning (strict: an error); the others are kept
+    doc["plans"].append({"form": 0, "N": 64, "K": 256, "m_lo": 1, "m_hi": 32, "tile": [3, 4, 1, 4], "split": 1})
+    path.write_text(json.dumps(doc))
+    with pytest.warns(UserWarning, match="skipped"):
+        assert Q.load_plan_table(str(path), replace=True) == 2
+    with pytest.raises(Q.QLinearError):
+        Q.load_plan_table(str(path), replace=True, strict=True)
 
 
 def test_shipped_table_is_well_formed():
@@ -95,8 +102,9 @@ def test_shipped_table_is_well_formed():
     lib = Q.load()
     lib.ql_gemm_plan_clear()
     try:
-        n = Q.load_plan_table(Q.PLAN_TABLE, replace=True)
+        n = Q.load_plan_table(Q.PLAN_TABLE, replace=True, strict=True)
         assert n == lib.ql_gemm_plan_count()
+        assert n == len(json.load(open(Q.PLAN_TABLE))["plans"])
     finally:
         lib.ql_gemm_plan_clear()
         Q.load_plan_table(Q.PLAN_TABLE)
