@@ -338,7 +338,10 @@ class ModelRunner:
             step(bs)                                                  # warm-up
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool):
+            # tensor-parallel ranks: RCCL's watchdog thread polls events while this thread captures; a capture in
+            # "thread_local" mode is not invalidated by what other threads of the process do
+            mode = "thread_local" if self.world_size > 1 else "global"
+            with torch.cuda.graph(g, pool, capture_error_mode=mode):
                 step(bs)
             if pool is None:
                 pool = g.pool()
