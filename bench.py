@@ -234,8 +234,13 @@ def measure_prefill_gemm(llm, M=16384):
     t = s.elapsed_time(e) * 1e-3 / 20
     flop = sum(2.0 * M * m.qw.shape[0] * m.qw.shape[1] for m in mods)
     tf = flop / t / 1e12
-    return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": None, "kernel": f"ql::qgemm_kernel (prefill W8A16 GEMM, four layer shapes, M = {M})"}
+    # the W8A16 kernels contract on bf16 MFMA (2.5 PFLOP/s dense); the fp8 W8A8 kernel on the K = 64 block-scaled fp8
+    # instruction (5 PFLOP/s dense); the timed region of a W8A8 module includes its activation-quantization launch
+    w8a8 = not getattr(mods[0], "weight_only", True)
+    peak = 5000.0 if (w8a8 and mods[0].dtype == torch.float8_e4m3fn) else 2500.0
+    form = "W8A8, activation quantization launch included" if w8a8 else "W8A16"
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+            "traffic": None, "kernel": f"ql::qgemm_kernel (prefill {form} GEMM, four layer shapes, M = {M})"}
 
 
 def measure_decode_attention(llm):

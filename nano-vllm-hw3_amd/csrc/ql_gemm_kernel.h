@@ -34,6 +34,9 @@
 namespace ql {
 
 enum { ACT_BF16 = 0, ACT_I8 = 1, ACT_FP8 = 2 };
+#ifndef QL_FP8_K64
+#define QL_FP8_K64 1          // fp8 x fp8 on the K = 64 block-scaled instruction (0: the K = 16 instruction pair)
+#endif
 
 constexpr int kCounterBytes = 64 * 1024;   // head of the workspace: one u32 ticket counter per output tile
 constexpr int kMaxTiles = kCounterBytes / 4;
@@ -450,6 +453,7 @@ void qgemm_kernel(const GemmParams p) {
             }
     };
     // one 32-k step of this wave: widen the 16 weight bytes of the lane, MT x (A fragment reads + MFMAs)
+    wreg_t w_even{};                                              // (fp8 x fp8: the even step's weights, see below)
     auto step = [&](auto chk, int buf, int kc, int c, const wreg_t w) {
         const int kb = kc + wk * C::KW + c * 32;   // first k of this step (wave-uniform)
         if (decltype(chk)::value && kb >= kend) return;
@@ -480,6 +484,32 @@ void qgemm_kernel(const GemmParams p) {
                 }
             }
         } else {
+            if constexpr (ACT == ACT_FP8 && !W16 && !DYNQ && QL_FP8_K64) {
+                // fp8 x fp8 at the chip's full fp8 rate: two 32-k steps per v_mfma_scale_f32_32x32x64_f8f6f4 (unit
+                // scales, e4m3 operands), which runs 64 k in the cycles the K = 16 instruction pair above takes for
+                // 32.  A lane's 32 operand bytes are its 16 of the even step and its 16 of the odd step, for A and
+                // B alike, so the contraction is again a permutation of the k sum.  The even step only parks its
+                // weights; a lone last step (K slice not a multiple of 64) takes the K = 16 path below.
+                typedef int i32x8 __attribute__((ext_vector_type(8)));
+                if ((c & 1) == 0 && (!decltype(chk)::value || kb + 32 < kend)) {
+                    w_even = w;
+                    return;
+                }
+                if (c & 1) {
+                    const int bc0 = base_c - APS;                  // the even step's first piece
+                    const int a_ev = buf * C::XBYTES + a_row + ((bc0 & ~SWZ_MASK) << 4) + (((bc0 & SWZ_MASK) << 4) ^ a_g4);
+                    const i32x8 bb = {w_even[0], w_even[1], w_even[2], w_even[3], w[0], w[1], w[2], w[3]};
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const i32x4 ae = *(const i32x4*)(smem + a_ev + i * 32 * RB);
+                        const i32x4 ao = *(const i32x4*)(smem + a0 + i * 32 * RB);
+                        const i32x8 aa = {ae[0], ae[1], ae[2], ae[3], ao[0], ao[1], ao[2], ao[3]};
+                        // (cbsz = blgp = 0: both operands e4m3; scale bytes 0x7F = 2^0)
+                        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aa, bb, acc[i], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const i32x4 a = *(const i32x4*)(smem + a0 + i * 32 * RB);
