@@ -219,6 +219,51 @@ def test_paged_attn_decode_lengths_around_the_kernel_steps(G):
         _close(out[b], ref, rtol=2 ** -6, atol=2e-2)
 
 
+@pytest.mark.parametrize("bs", [16, 128, 384, 512, 1024])
+@pytest.mark.parametrize("G", [2, 4])
+def test_paged_attn_decode_long_contexts_and_block_sizes(G, bs):
+    """Sequences of up to twelve 512-token chunks (the merge launch beyond a handful of chunk states) over caches whose
+    block is smaller than, equal to, not a divisor of, and larger than the chunk (a chunk then spans many, two or
+    one block); the quantizing merge stays bit-identical to per_row_quant of the plain output."""
+    from nanovllm import ops
+    from nanovllm.utils import quantization as NQ
+    torch.manual_seed(17 + bs)
+    Hkv, D = 2, 128
+    Hq = Hkv * G
+    lens = [4095, 4096, 4097, 6100, 2049, 513, 1]
+    B = len(lens)
+    width = (max(lens) + bs - 1) // bs
+    nblk = sum((l + bs - 1) // bs for l in lens) + 1
+    kc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    order = (torch.randperm(nblk - 1) + 1).tolist()
+    tables = torch.zeros(B, width, dtype=torch.int32)
+    for b, l in enumerate(lens):
+        for j in range((l + bs - 1) // bs):
+            tables[b, j] = order.pop()
+    tables = tables.cuda()
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.bfloat16)
+    ctx = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ops.reserve_attn_workspace(B, Hq, Hkv, bs, width, "cuda")
+    out = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5)
+    for b, l in enumerate(lens):
+        nb = (l + bs - 1) // bs
+        idx = (tables[b, :nb].long()[:, None] * bs + torch.arange(bs, device="cuda")[None, :]).reshape(-1)[:l]
+        k = kc.view(-1, Hkv, D)[idx].float().repeat_interleave(G, dim=1)
+        v = vc.view(-1, Hkv, D)[idx].float().repeat_interleave(G, dim=1)
+        s = torch.einsum("hd,lhd->hl", q[b].float(), k) * D ** -0.5
+        ref = torch.einsum("hl,lhd->hd", s.softmax(-1), v)
+        _close(out[b], ref, rtol=2 ** -6, atol=2e-2)
+    out2, rm = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5, return_rowmax=True)
+    assert torch.equal(out2, out)
+    assert torch.equal(rm, out.view(B, Hkv, G * D).float().abs().amax(-1))
+    for qd in (torch.int8, torch.float8_e4m3fn):
+        out3, qx, sx = ops.paged_attn_decode(q, kc, vc, tables, ctx, D ** -0.5, quant_dtype=qd)
+        assert torch.equal(out3, out)
+        qr, sr = NQ.per_row_quant(out.view(B, Hq * D), qd)
+        assert torch.equal(sx, sr) and torch.equal(qx.view(torch.uint8), qr.view(torch.uint8))
+
+
 @pytest.mark.parametrize("G", [1, 2, 4, 5, 8])
 def test_attn_prefill_varlen_matches_torch(G):
     """Packed causal self-attention against an fp32 softmax(QK^T)V per sequence; lengths straddle the
