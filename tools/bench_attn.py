@@ -10,14 +10,15 @@ nblk = int(((lens + bs - 1) // bs).sum()) + 1
 L = 8   # layers' worth of distinct caches so that the KV streams from HBM
 kc = [torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16) for _ in range(L)]
 vc = [torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16) for _ in range(L)]
-tables = torch.zeros(B, 16, dtype=torch.int32, device="cuda")
+W = int(os.environ.get("WIDTH", "16"))          # block-table width: 16 = max_model_len 4096; the grid has W / 2 chunks
+tables = torch.zeros(B, W, dtype=torch.int32, device="cuda")
 nxt = 1
 for b in range(B):
     for j in range((int(lens[b]) + bs - 1) // bs):
         tables[b, j] = nxt; nxt += 1
 q = torch.randn(B, Hq, D, device="cuda", dtype=torch.bfloat16)
 ctx = lens.to(torch.int32).cuda()
-ops.reserve_attn_workspace(B, Hq, Hkv, bs, 16)
+ops.reserve_attn_workspace(B, Hq, Hkv, bs, W)
 for i in range(L): ops.paged_attn_decode(q, kc[i], vc[i], tables, ctx, D ** -0.5)
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
