@@ -33,6 +33,10 @@ MODELS = {
     "4b": (32, 8, 2560, 9728),
     "8b": (32, 8, 4096, 12288),
     "8b_tp8": (4, 1, 4096, 1536),
+    # the headline model's rank-local layers under tensor parallelism (bench.py --gpus 2 / 4 / 8)
+    "0.6b_tp2": (8, 4, 1024, 1536),
+    "0.6b_tp4": (4, 2, 1024, 768),
+    "0.6b_tp8": (2, 1, 1024, 384),
 }
 TILES = BK.TILES
 ROPE_TILES = [(1, 4, 2, 16), (1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4)]
