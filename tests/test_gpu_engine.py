@@ -264,6 +264,43 @@ def test_paged_attn_decode_long_contexts_and_block_sizes(G, bs):
         assert torch.equal(sx, sr) and torch.equal(qx.view(torch.uint8), qr.view(torch.uint8))
 
 
+def test_paged_attn_decode_bench_size_properties():
+    """At the benchmark's size (256 sequences of 100-2047 cached tokens, Qwen3-0.6B heads) the properties that need no
+    reference: the same call twice gives the same bits, a sequence run alone gives the bits it has inside the batch, and
+    moving every sequence's tokens to other physical cache blocks (tables rewritten accordingly) changes nothing."""
+    from nanovllm import ops
+    g = torch.Generator().manual_seed(23)
+    B, Hq, Hkv, D, bs, width = 256, 16, 8, 128, 256, 8
+    lens = torch.randint(100, 2048, (B,), generator=g)
+    nb = (lens + bs - 1) // bs
+    nblk = int(nb.sum()) + 1
+    kc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn(nblk, bs, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    tables = torch.zeros(B, width, dtype=torch.int32)
+    nxt = 1
+    for b in range(B):
+        for j in range(int(nb[b])):
+            tables[b, j] = nxt
+            nxt += 1
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.bfloat16)
+    ctx = lens.to(torch.int32).cuda()
+    ops.reserve_attn_workspace(B, Hq, Hkv, bs, width, "cuda")
+    out = ops.paged_attn_decode(q, kc, vc, tables.cuda(), ctx, D ** -0.5)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(ops.paged_attn_decode(q, kc, vc, tables.cuda(), ctx, D ** -0.5), out)
+    for b in (0, 17, 255, int(lens.argmax()), int(lens.argmin())):
+        alone = ops.paged_attn_decode(q[b:b + 1].contiguous(), kc, vc, tables[b:b + 1].cuda(), ctx[b:b + 1].contiguous(),
+                                      D ** -0.5)
+        assert torch.equal(alone[0], out[b])
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), torch.randperm(nblk - 1, generator=g) + 1])   # old block -> new
+    kc2, vc2 = torch.empty_like(kc), torch.empty_like(vc)
+    kc2[perm.cuda()] = kc
+    vc2[perm.cuda()] = vc
+    tables2 = perm[tables.long()].to(torch.int32)
+    tables2[tables == 0] = 0
+    assert torch.equal(ops.paged_attn_decode(q, kc2, vc2, tables2.cuda(), ctx, D ** -0.5), out)
+
+
 @pytest.mark.parametrize("G", [1, 2, 4, 5, 8])
 def test_attn_prefill_varlen_matches_torch(G):
     """Packed causal self-attention against an fp32 softmax(QK^T)V per sequence; lengths straddle the
