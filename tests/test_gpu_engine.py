@@ -427,6 +427,39 @@ def test_engine_quantized_variants(tiny_dir, kw):
     assert rel < 0.1, float(rel)
 
 
+def test_attn_prefill_bench_size_properties():
+    """One prefill batch of the benchmark's size (16,384 packed tokens, Qwen3-0.6B heads): the same call twice gives
+    the same bits, a sequence packed alone gives the bits it has inside the batch, and - causality - the first n rows
+    of a sequence do not depend on the tokens after them (the sequence cut to n tokens gives the same bits)."""
+    from nanovllm import ops
+    g = torch.Generator().manual_seed(29)
+    Hq, Hkv, D = 16, 8, 128
+    lens = []
+    while sum(lens) < 16384 - 1024:
+        lens.append(int(torch.randint(100, 1025, (1,), generator=g)))
+    lens.append(16384 - sum(lens))
+    T = sum(lens)
+    cu = [0]
+    for l in lens:
+        cu.append(cu[-1] + l)
+    q = torch.randn(T, Hq, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(T, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(T, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device="cuda")
+    out = ops.attn_prefill(q, k, v, cu_t, max(lens), D ** -0.5)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(ops.attn_prefill(q, k, v, cu_t, max(lens), D ** -0.5), out)
+    for s in (0, len(lens) // 2, len(lens) - 1):
+        a, b = cu[s], cu[s + 1]
+        one = torch.tensor([0, b - a], dtype=torch.int32, device="cuda")
+        alone = ops.attn_prefill(q[a:b].contiguous(), k[a:b].contiguous(), v[a:b].contiguous(), one, b - a, D ** -0.5)
+        assert torch.equal(alone, out[a:b])
+        for n in (1, 33, (b - a) // 2, b - a - 1):
+            cut = torch.tensor([0, n], dtype=torch.int32, device="cuda")
+            head = ops.attn_prefill(q[a:a + n].contiguous(), k[a:a + n].contiguous(), v[a:a + n].contiguous(), cut, n, D ** -0.5)
+            assert torch.equal(head, out[a:a + n])
+
+
 @pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn])
 def test_w8a8_engine_without_activation_quant_launches(tiny_dir, dtype):
     """W8A8 engine with NANOVLLM_DYNQ: o_proj and down_proj quantize their input inside the GEMM from the partial
