@@ -135,12 +135,15 @@ int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, con
  * GEMM followed by ql_silu_mul.  The weight must be PRE-ARRANGED by the caller: with I = N/2 and the
  * usual packed rows (gate rows [0,I), up rows [I,2I)), row 64*s + j of qw (and of sw / the group
  * scales / bias) holds gate row 32*s + j for j < 32 and up row 32*s + j - 32 for j >= 32.
- * Requires N % 64 == 0; never splits K across workgroups, so no workspace. */
+ * Requires N % 64 == 0.  Workspace as for the plain GEMMs (ql_gemm_workspace_bytes covers this form): when K is
+ * split across workgroups, gate and up meet in the epilogue of the tile's last workgroup, which holds the whole
+ * reduced tile. */
 int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
                        const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
-                       void* stream);
+                       void* workspace, size_t workspace_bytes, void* stream);
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
-                      const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, void* stream);
+                      const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* per_row_matmul (nanovllm/utils/quantization.py:310-346) with its per_row_quant(x) (:323) inside the GEMM: x is the
  * bf16 activation matrix, rowmax_part f32 [M, nparts] holds partial |max| values of every row over ANY split of its
@@ -155,7 +158,7 @@ int ql_row_absmax_parts(const void* x_bf16, int64_t T, int64_t H, int parts, flo
  * gate_up_proj -> SiluAndMul -> down_proj, whose per_row_quant(x) of quantization.py:323 then needs no launch). */
 int ql_gemm_w8a8_silu_rowmax(int dtype, const void* qx, const float* sx, const void* qw, const float* sw,
                              const void* bias_bf16, void* y_bf16, float* rowmax_part_out, int64_t M, int64_t N, int64_t K,
-                             void* stream);
+                             void* workspace, size_t workspace_bytes, void* stream);
 int ql_gemm_w8a8_dynq(int dtype, const void* x_bf16, const float* rowmax_part, int nparts, const void* qw,
                       const float* sw, const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K,
                       void* workspace, size_t workspace_bytes, void* stream);
@@ -210,8 +213,9 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
 /* Tuning hook for benchmarks/tests: force the tile configuration of the next GEMM calls made by
  * this thread.  mt = 32-row fragments per wave (1,2,4,8), wn x wk = how the block's 4 waves split
  * N and K ((4,1),(2,2),(1,4)), cp = 32-k steps a wave loads per chunk (2,4,8), split_k = K slices
- * across workgroups.  mt = wn = wk = cp = 0 restores the built-in tile heuristic, split_k <= 0 the
- * split heuristic.  Returns QL_EINVAL for a tile that is not built.  A forced split needs the
+ * across workgroups, or, negative, the stream-K schedule on -split_k workgroups (weight-only GEMMs on the
+ * tiles built for it; see ql_gemm_plan_set).  mt = wn = wk = cp = 0 restores the built-in tile heuristic,
+ * split_k = 0 the split heuristic.  Returns QL_EINVAL for a tile that is not built.  A forced split needs the
  * workspace size that ql_gemm_workspace_bytes reports while the configuration is forced. */
 int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k);
 
@@ -223,7 +227,11 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k);
  * the launch (0 = plain per-row / per-tensor W8A16).  With QL_PLAN_PARTIAL the entry is for the deferred
  * split-K form (ql_gemm_*_partial; split_k = 1 there means "do not defer").  Entries of one form and
  * shape must not overlap; a tile that is not built for the form, or a split the form cannot run, is
- * QL_EINVAL.  ql_gemm_workspace_bytes / _max_bytes see the table, so set entries before sizing a
+ * QL_EINVAL.  split_k = -G (8 <= G <= 4096) selects the STREAM-K schedule for the weight-only forms: a 1-D grid
+ * of G workgroups (normally one or two per CU) shares the (output tile, k chunk) units of the problem evenly,
+ * each workgroup taking one contiguous range, and tiles that several workgroups share are combined like split-K
+ * tiles (ascending k order, bit-reproducible); it keeps every CU busy when the tile count does not fill whole
+ * rounds of the chip (152 tiles of 128 x 256 for a Qwen3-4B gate/up projection at 256 rows).  ql_gemm_workspace_bytes / _max_bytes see the table, so set entries before sizing a
  * workspace.  ql_gemm_plan_query writes {mt, wn, wk, cp, split_k} of the plan a call would run to out[5]. */
 #define QL_PLAN_GROUP 1    /* per-group scales */
 #define QL_PLAN_SILU 2     /* ql_gemm_*_silu */

@@ -31,7 +31,27 @@ static bool rope_tile_built(int mt, int wn, int wk, int cp) {
     return false;
 }
 
-struct Plan { int mt, wn, wk, cp, split, k_per_split; dim3 grid; bool pair_rows = false; };
+struct Plan {
+    int mt, wn, wk, cp, split, k_per_split;
+    dim3 grid;
+    bool pair_rows = false;
+    // stream-K schedule (sk_G > 0; `split` is then reported as -sk_G): workgroups, row tiles walked side by side,
+    // k chunks per output tile, column / row tiles of the problem
+    int sk_G = 0, sk_R = 1, sk_C = 0, sk_nb = 0, sk_mb = 0;
+};
+
+// tiles built with the stream-K schedule (QL_TILE_LIST_SK*, ql_gemm_kernel.h)
+static bool sk_tile_built(int mt, int wn, int wk, int cp, bool group, bool rope) {
+    if (rope) {
+#define QL_ROW(MT_, WN_, WK_, CP_, DB_) if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) return true;
+        QL_TILE_LIST_SK_ROPE(QL_ROW)
+        return false;
+    }
+    QL_TILE_LIST_SK(QL_ROW)
+    if (!group) { QL_TILE_LIST_SK_TALL(QL_ROW) }
+#undef QL_ROW
+    return false;
+}
 
 // GemmParams::gmagic for a group size (a multiple of 32): with d = group / 32 and m = ceil(2^32 / d),
 // umulhi(q, m) == q / d for all q < 2^32 / d, far beyond any K / 32 that passes check_common
@@ -157,9 +177,34 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool group, bool silu = f
     if (base < 144) split = K >= 8192 ? (K + 2047) / 2048 : (K + 1023) / 1024;
     else if (base < 160 && pick < nladder - 1) split = (K + 1023) / 1024;
     else if (base < 512 && K >= 4096) split = (K + 4095) / 4096;   // long K: at most four chunks per slice
-    if (t_split > 0) split = t_split;
-    if (f_split > 0) split = f_split;
-    if (silu) split = 1;                                    // gate and up meet in the epilogue of ONE workgroup
+    // (gate/up with the SiLU epilogue: gate and up meet in the tile's LAST workgroup, which holds the whole reduced
+    // tile; the heuristics were measured without slices there and keep one, a table entry may ask for more)
+    if (silu) split = 1;
+    if (t_split != 0) split = t_split;
+    if (f_split != 0) split = f_split;
+    if (split < 0) {
+        // stream-K: -split workgroups share the (tile, chunk) units evenly (see the kernel)
+        // (never more workgroups than units: a workgroup without units would be counted among a tile's
+        // contributors and never arrive)
+        const int64_t G = std::min<int64_t>(-split, base * kchunks);
+        static const bool no_pair = getenv("QL_SK_NOPAIR") != nullptr;
+        // (the kernel divides by multiply-high: units x chunks per tile and units x units per workgroup below 2^32)
+        const int64_t U = base * kchunks;
+        if (sk_tile_built(mt, wn, wk, cp, group, rope) && !w8a8 && base <= kMaxTiles && G >= 1 && U * kchunks < (1ll << 31) &&
+            U * (U / G + 2) < (1ll << 31)) {
+            pl.split = (int)-G;
+            pl.k_per_split = (int)(kchunks * kb);
+            pl.sk_G = (int)G;
+            pl.sk_R = (!no_pair && mblocks > 1 && mblocks <= 8 && G % (8 * mblocks) == 0 && G / mblocks <= nblocks * kchunks)
+                          ? (int)mblocks : 1;
+            pl.sk_C = (int)kchunks;
+            pl.sk_nb = (int)nblocks;
+            pl.sk_mb = (int)mblocks;
+            pl.grid = dim3((unsigned)G, 1, 1);
+            return pl;
+        }
+        split = 1;
+    }
     if (split > 64) split = 64;
     if (split > kchunks) split = kchunks;
     if (base > kMaxTiles) split = 1;                        // one ticket counter per output tile
@@ -217,6 +262,8 @@ static Plan make_plan_partial(int64_t M, int64_t N, int64_t K, bool group) {
 }
 
 static size_t plan_workspace(const Plan& pl) {
+    if (pl.sk_G > 0)    // one slab per (workgroup, tile) pair that shares a tile: at most G + tiles of them
+        return (size_t)kCounterBytes + ((size_t)pl.sk_G + (size_t)pl.sk_nb * pl.sk_mb) * (size_t)(pl.wn * pl.mt * 16 * 64 * 4);
     if (pl.split <= 1) return 0;
     const size_t tiles = (size_t)pl.grid.x * pl.grid.y;
     return (size_t)kCounterBytes + tiles * pl.split * (size_t)(pl.wn * pl.mt * 16 * 64 * 4);
@@ -237,6 +284,30 @@ static int check_common(const char* fn, int64_t M, int64_t N, int64_t K) {
 static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_bytes, hipStream_t s, const char* fn) {
     if (!k) { set_error("%s: tile (%d,%d,%d,%d) not built", fn, pl.mt, pl.wn, pl.wk, pl.cp); return QL_EINVAL; }
     p.k_per_split = pl.k_per_split;
+    if (pl.sk_G > 0) {
+        const size_t need = plan_workspace(pl);
+        if (!ws || ws_bytes < need) {
+            set_error("%s: workspace of %zu bytes needed for the stream-K schedule on %d workgroups, got %zu", fn, need, pl.sk_G, ws_bytes);
+            return QL_EWORKSPACE;
+        }
+        p.counters = (unsigned*)ws;
+        p.partial = (unsigned char*)ws + kCounterBytes;
+        p.sk_G = pl.sk_G; p.sk_C = pl.sk_C; p.sk_R = pl.sk_R; p.sk_mblocks = pl.sk_mb;
+        {
+            // (make_plan checked that every dividend times its divisor stays below 2^32)
+            auto magic = [](int64_t d) -> unsigned { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
+            const int64_t Gr = pl.sk_G / pl.sk_R;
+            const int64_t Ul = (pl.sk_R > 1 ? (int64_t)pl.sk_nb : (int64_t)pl.sk_nb * pl.sk_mb) * pl.sk_C;
+            p.sk_Gr = (int)Gr; p.sk_per = (int)(Ul / Gr); p.sk_rem = (int)(Ul % Gr);
+            p.sk_mC = magic(pl.sk_C); p.sk_mper = magic(p.sk_per); p.sk_mper1 = magic(p.sk_per + 1);
+            p.sk_mmb = magic(pl.sk_mb); p.sk_mR = magic(pl.sk_R);
+        }
+        p.swz_gn = 0;
+        p.ntile_n = pl.sk_nb;
+        hipLaunchKernelGGL(k, pl.grid, dim3(64 * pl.wn * pl.wk), 0, s, p);
+        QL_CHECK_LAUNCH(fn);
+        return QL_OK;
+    }
     if (pl.split > 1) {
         const size_t need = plan_workspace(pl);
         if (!ws || ws_bytes < need) {
@@ -283,9 +354,12 @@ size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity)
     size_t need = plan_workspace(make_plan(M, N, K, grp));
     const bool heads = N % 128 == 0;
     if (heads) need = std::max(need, plan_workspace(make_plan(M, N, K, grp, false, true)));
+    const bool strips = N % 64 == 0;
+    if (strips) need = std::max(need, plan_workspace(make_plan(M, N, K, grp, true)));
     if (!grp) {
         need = std::max(need, plan_workspace(make_plan(M, N, K, false, false, false, true)));
         if (heads) need = std::max(need, plan_workspace(make_plan(M, N, K, false, false, true, true)));
+        if (strips) need = std::max(need, plan_workspace(make_plan(M, N, K, false, true, false, true)));
     }
     return need;
 }
@@ -301,6 +375,16 @@ size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int gran
         if (b > need) need = b;
         if (mm == max_M) break;
     }
+    // ... of the heuristics; a table entry may begin or end anywhere: the ends of every entry for this (N, K) as well
+    std::vector<int64_t> ends;
+    {
+        std::shared_lock<std::shared_mutex> lock(g_plans_mu);
+        for (const auto& kv : g_plans)
+            if (std::get<1>(kv.first) == N && std::get<2>(kv.first) == K)
+                for (const PlanEntry& e : kv.second) { ends.push_back(e.m_lo); ends.push_back(e.m_hi); }
+    }
+    for (int64_t m : ends)
+        if (m >= 1 && m <= max_M) need = std::max(need, ql_gemm_workspace_bytes(m, N, K, granularity));
     return need;
 }
 
@@ -314,7 +398,7 @@ int ql_gemm_force_config(int mt, int wn, int wk, int cp, int split_k) {
     f_wn = any ? wn : 0;
     f_wk = any ? wk : 0;
     f_cp = any ? cp : 0;
-    f_split = split_k > 0 ? split_k : 0;
+    f_split = split_k;                                       // (< 0: the stream-K schedule on -split_k workgroups)
     return QL_OK;
 }
 
@@ -324,13 +408,14 @@ int ql_gemm_plan_set(int form, int64_t m_lo, int64_t m_hi, int64_t N, int64_t K,
     const bool group = (form & QL_PLAN_GROUP) != 0, silu = (form & QL_PLAN_SILU) != 0, rope = (form & QL_PLAN_ROPE) != 0;
     const bool partial = (form & QL_PLAN_PARTIAL) != 0;
     if (form < 0 || (form & ~known) || (silu && rope) || (partial && (silu || rope)) || ((form & QL_PLAN_W8A8) && group) ||
-        m_lo < 1 || m_hi < m_lo || N <= 0 || K <= 0 || K % 32 || split_k < 1 || split_k > 64) {
+        m_lo < 1 || m_hi < m_lo || N <= 0 || K <= 0 || K % 32 || split_k == 0 || split_k > 64 || split_k < -4096 ||
+        (split_k < 0 && (partial || (form & QL_PLAN_W8A8)))) {
         set_error("%s: bad argument (form=%d rows %lld..%lld N=%lld K=%lld split=%d)", fn, form, (long long)m_lo,
                   (long long)m_hi, (long long)N, (long long)K, split_k);
         return QL_EINVAL;
     }
-    if (!tile_built(mt, wn, wk, cp, group) || (silu && ((wn & 1) || split_k != 1)) || (rope && !rope_tile_built(mt, wn, wk, cp)) ||
-        (rope && N % 128)) {
+    if (!tile_built(mt, wn, wk, cp, group) || (silu && (wn & 1)) || (rope && !rope_tile_built(mt, wn, wk, cp)) ||
+        (rope && N % 128) || (split_k < 0 && !sk_tile_built(mt, wn, wk, cp, group, rope))) {
         set_error("%s: tile (mt=%d, wn=%d, wk=%d, cp=%d) with %d slices cannot run form %d", fn, mt, wn, wk, cp, split_k, form);
         return QL_EINVAL;
     }
@@ -426,7 +511,10 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     const Plan pl = make_plan(M, N, K, grp, silu, rope != nullptr);
     kern_t k;
     const bool rp = rope != nullptr;
-    if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
+    if (pl.sk_G > 0) {
+        if (wdtype == QL_INT8) k = grp ? pick_sk_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_sk_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
+        else k = grp ? pick_sk_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_sk_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
+    } else if (wdtype == QL_INT8) k = grp ? pick_bf16_i8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_bf16_i8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
     else k = grp ? pick_bf16_fp8_group(pl.mt, pl.wn, pl.wk, pl.cp, rp) : pick_bf16_fp8_row(pl.mt, pl.wn, pl.wk, pl.cp, rp);
     return run(k, p, pl, workspace, workspace_bytes, as_stream(stream), fn);
 }
@@ -573,9 +661,10 @@ int ql_gemm_w8a8_partial(int dtype, const void* qx, const void* qw, int64_t M, i
 }
 
 int ql_gemm_w8a16_silu(int wdtype, int granularity, const void* x, const void* qw, const float* sw, const void* bias,
-                       void* y, int64_t M, int64_t N, int64_t K, int group, void* stream) {
-    return gemm_w8a16("ql_gemm_w8a16_silu", true, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, nullptr, 0,
-                      stream);
+                       void* y, int64_t M, int64_t N, int64_t K, int group, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    return gemm_w8a16("ql_gemm_w8a16_silu", true, wdtype, granularity, x, qw, sw, bias, y, M, N, K, group, workspace,
+                      workspace_bytes, stream);
 }
 
 int ql_gemm_w8a8(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
@@ -616,15 +705,16 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
 }
 
 int ql_gemm_w8a8_silu(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
-                      void* y, int64_t M, int64_t N, int64_t K, void* stream) {
-    return gemm_w8a8("ql_gemm_w8a8_silu", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream);
+                      void* y, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_w8a8("ql_gemm_w8a8_silu", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, workspace, workspace_bytes, stream);
 }
 
 int ql_gemm_w8a8_silu_rowmax(int dtype, const void* qx, const float* sx, const void* qw, const float* sw, const void* bias,
-                             void* y, float* rowmax_part_out, int64_t M, int64_t N, int64_t K, void* stream) {
+                             void* y, float* rowmax_part_out, int64_t M, int64_t N, int64_t K, void* workspace,
+                             size_t workspace_bytes, void* stream) {
     if (M > 0 && !rowmax_part_out) { set_error("ql_gemm_w8a8_silu_rowmax: bad argument"); return QL_EINVAL; }
-    return gemm_w8a8("ql_gemm_w8a8_silu_rowmax", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, nullptr, 0, stream, nullptr,
-                     nullptr, 0, rowmax_part_out);
+    return gemm_w8a8("ql_gemm_w8a8_silu_rowmax", true, dtype, qx, sx, qw, sw, bias, y, M, N, K, workspace, workspace_bytes,
+                     stream, nullptr, nullptr, 0, rowmax_part_out);
 }
 
 int ql_gemm_w8a8_dynq(int dtype, const void* x, const float* rowmax_part, int nparts, const void* qw, const float* sw,

@@ -73,6 +73,18 @@ struct GemmParams {
                                  // the bf16 the plain kernel would store, its smallest column}, reduced by argmax_finish
     int rope_on;                 // 1 on the ROPE kernels (qkv projection: y is not stored; q/k norm + RoPE + KV store in the epilogue)
     RopeArgs rope;
+    // Stream-K schedule (SK kernels): a 1-D grid of sk_G workgroups shares the (output tile, k chunk) units evenly,
+    // each workgroup taking one contiguous range of them (see the kernel).  ntile_n = column tiles.
+    int sk_G;                    // workgroups of the grid
+    int sk_C;                    // k chunks (of the tile's KB) per output tile
+    int sk_R;                    // row tiles that walk the same (column tile, chunk) range side by side on one XCD: all
+                                 // of the problem's row tiles, or 1 (row tiles are then units like any other)
+    int sk_mblocks;              // row tiles of the problem
+    // the schedule's divisions as multiply-high (an integer division is ~30 dependent instructions, and the
+    // schedule needs ten of them before a workgroup's first load): umulhi(n, ceil(2^32 / d)) == n / d while n d < 2^32
+    // (0 stands for d = 1).  per = units per workgroup (the first `rem` workgroups of a unit range take one more).
+    int sk_Gr, sk_per, sk_rem;
+    unsigned sk_mC, sk_mper, sk_mper1, sk_mmb, sk_mR;
 };
 
 typedef void (*kern_t)(const GemmParams);
@@ -158,16 +170,19 @@ struct Cfg {
 };
 
 template <int ACT, bool FP8W, int MT, int WN, int WK, int CP, bool DB, bool GROUP, bool ROPE = false, bool W16 = false,
-          bool AMAX = false, bool DYNQ = false>
+          bool AMAX = false, bool DYNQ = false, bool SK = false>
 // (second launch bound = waves per SIMD the register allocation must leave room for: the 128 x 256 weight-only tile
 // with 64-k chunks is held to 128 registers so that TWO of its 8-wave workgroups share a CU and one's prologue and
 // epilogue run under the other's MFMAs - worth more on the K <= 2048 shapes than the registers it gives up)
-__global__ __launch_bounds__(64 * WN * WK, (ACT == ACT_BF16 && MT == 4 && WN == 8 && WK == 1 && CP == 2 && !GROUP && !W16) ? 4 : 1)
+// (likewise the 64 x 128 tile on the stream-K schedule, whose segment loop costs it a dozen registers)
+__global__ __launch_bounds__(64 * WN * WK, ((ACT == ACT_BF16 && MT == 4 && WN == 8 && WK == 1 && CP == 2 && !GROUP && !W16) ||
+                                            (SK && ACT == ACT_BF16 && MT == 2 && WN == 4 && WK == 2 && CP == 4 && !GROUP)) ? 4 : 1)
 void qgemm_kernel(const GemmParams p) {
     static_assert(!ROPE || WN == 4 || WN == 8, "the qkv epilogue needs whole 128-column heads per workgroup");
     static_assert(!W16 || (ACT == ACT_BF16 && !GROUP && !ROPE && !FP8W), "16-bit weights: plain bf16 x bf16");
     static_assert(!AMAX || (W16 && WK == 1 && WN >= 4), "the sampler epilogue is built for the output projection's tiles");
     static_assert(!DYNQ || (ACT != ACT_BF16 && !ROPE && !W16 && !GROUP), "dynamic activation quantization: the W8A8 kernels");
+    static_assert(!SK || (!W16 && !AMAX && !DYNQ), "the stream-K schedule is built for the quantized-weight GEMMs");
     using wreg_t = typename std::conditional<W16, W2, i32x4>::type;
     using xreg_t = typename std::conditional<DYNQ, W2, i32x4>::type;   // one staged piece: 16 activations as they lie in memory
     using C = Cfg<ACT, MT, WN, WK, CP, DB>;
@@ -201,21 +216,38 @@ void qgemm_kernel(const GemmParams p) {
     // The kernel is VALU-issue-bound at decode sizes, so everything that is uniform per wave is kept
     // in scalar registers (the wave index is made provably uniform) and every per-lane address is
     // split into a lane-constant part computed once and a uniform part.
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % WN;
-    const int wk = wave / WN;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
     // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so with the
     // plain (x = N tile, y = M tile) order every XCD touches every activation tile.  For prefill-sized grids the
     // host asks for an XCD-aware order instead: the XCDs form a (8/gn) x gn grid over (M tiles, N tiles); one XCD
     // walks its N tiles fastest, so concurrent workgroups share an activation tile in L2 and the XCD's slice of
     // the weights (N*K/gn bytes) stays L2-resident.
     unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (p.swz_gn < 0) {
+    // Stream-K (SK kernels).  A grid of p.sk_G workgroups, about one or two per CU, shares the problem's
+    // (output tile, k chunk) units evenly: workgroup g takes U / G (+ 1) consecutive units of the tile-major order,
+    // i.e. the end of one tile's K range, whole tiles, and the start of another's.  Every CU is busy for the same
+    // time whatever the tile count (152 tiles of 128 x 256 on 256 CUs otherwise leave 104 of them idle), and a tile
+    // that several workgroups share is combined exactly like a split-K tile: slabs, a ticket per tile, the last
+    // arriver sums the slabs in ascending k order.  With sk_R row tiles the workgroups (w >> 3) % R = 0..R-1 of one
+    // XCD walk the same (column tile, chunk) range on the R row tiles at the same time, so the weights they share
+    // come from HBM once and from that XCD's L2 afterwards.
+    int sk_u = 0, sk_uend = 0, sk_g = 0, sk_lane = 0, sk_Tl = 0;
+    auto mdiv = [](unsigned n, unsigned magic) -> unsigned { return magic ? __umulhi(n, magic) : n; };
+    if constexpr (SK) {
+        const unsigned w = blockIdx.x, R = (unsigned)p.sk_R;
+        if (R > 1) {
+            const unsigned q8 = w >> 3, qq = mdiv(q8, p.sk_mR);
+            sk_lane = (int)(q8 - qq * R);
+            sk_g = (int)((w & 7u) + 8u * qq);
+        } else {
+            sk_g = (int)w;
+        }
+        sk_Tl = R > 1 ? p.ntile_n : p.ntile_n * p.sk_mblocks;
+        // unit range of workgroup g: `per` units, one more for the first `rem` workgroups
+        sk_u = sk_g * p.sk_per + min(sk_g, p.sk_rem);
+        sk_uend = sk_u + p.sk_per + (sk_g < p.sk_rem ? 1 : 0);
+    }
+    if (SK) {
+    } else if (p.swz_gn < 0) {
         // Few row tiles over a long weight stream (the output projection at 129+ rows): workgroup ids are dealt
         // round-robin over the XCDs, so ids 8 apart run on the same XCD at about the same time; giving them the
         // same column tile makes the second row tile's weight reads L2 hits instead of a second pass over HBM.
@@ -229,10 +261,48 @@ void qgemm_kernel(const GemmParams p) {
         bx = (xcd % gn) * ntl + idx % ntl;
         by = (idx / ntl) * gm + xcd / gn;
     }
+    do {                                                          // (one pass unless SK: a pass per tile segment)
+    int tid = threadIdx.x;
+    // (SK: opaque per segment.  Otherwise every lane-constant address part below is loop-invariant, gets hoisted out
+    // of the segment loop and stays live through the main loop: 56 more registers on the 64 x 128 tile)
+    if constexpr (SK) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN;
+    const int wk = wave / WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    int k0, kend, S, slot;
+    unsigned tile_id, slab0;                                      // ticket of the tile; slab of its first contributor
+    if constexpr (SK) {
+        const int Cn = p.sk_C;
+        const int tl = (int)mdiv((unsigned)sk_u, p.sk_mC), c0 = sk_u - tl * Cn, c1 = min(Cn, c0 + (sk_uend - sk_u));
+        if (p.sk_R > 1) { bx = (unsigned)tl; by = (unsigned)sk_lane; }
+        else { bx = mdiv((unsigned)tl, p.sk_mmb); by = (unsigned)tl - bx * (unsigned)p.sk_mblocks; }
+        k0 = c0 * C::KB;
+        kend = min(p.K, c1 * C::KB);
+        // the workgroups that hold units of this tile: owner(u) = the g whose unit range contains u
+        const int thr = p.sk_rem * (p.sk_per + 1);
+        auto owner = [&](int u) -> int {
+            return u < thr ? (int)mdiv((unsigned)u, p.sk_mper1) : p.sk_rem + (int)mdiv((unsigned)(u - thr), p.sk_mper);
+        };
+        const int gfirst = owner(tl * Cn), glast = owner(tl * Cn + Cn - 1);
+        S = glast - gfirst + 1;
+        slot = sk_g - gfirst;
+        tile_id = by * (unsigned)p.ntile_n + bx;
+        // (workgroup, tile) pairs that share a tile ascend in g + tile: G + T slabs hold them all
+        slab0 = (unsigned)(sk_lane * (p.sk_Gr + sk_Tl) + gfirst + tl);
+        sk_u += c1 - c0;
+    } else {
+        k0 = blockIdx.z * p.k_per_split;
+        kend = min(p.K, k0 + p.k_per_split);
+        S = gridDim.z;
+        slot = blockIdx.z;
+        tile_id = by * gridDim.x + bx;
+        slab0 = tile_id * (unsigned)S;
+    }
     const int m0 = by * C::BM;
     const int n0 = bx * C::BN + wn * 32;
-    const int k0 = blockIdx.z * p.k_per_split;
-    const int kend = min(p.K, k0 + p.k_per_split);
     const int nchunks = (kend - k0 + C::KB - 1) / C::KB;
     const bool fullM = (m0 + C::BM <= p.M);
 
@@ -269,12 +339,12 @@ void qgemm_kernel(const GemmParams p) {
     // position, norm weights) is requested NOW, so that this chain of dependent reads is over long before the tail
     // (only where one pass of the workgroup's threads covers the tile, i.e. the decode tiles: there the tail's
     // latency is what counts; the large prefill tiles have no registers to spare and load at the tail)
-    constexpr bool ROPE_EARLY = ROPE && (C::BM * (C::BN / 128) * 8 <= C::NT);
+    constexpr bool ROPE_EARLY = ROPE && !SK && (C::BM * (C::BN / 128) * 8 <= C::NT);
     RopePre rope_pre;
     if constexpr (ROPE_EARLY) {
         constexpr int HPT = C::BN / 128;
         const int row = (tid >> 3) / HPT, hh = (tid >> 3) % HPT;
-        if (tid < C::BM * HPT * 8 && m0 + row < p.M)
+        if (tid < C::BM * HPT * 8 && m0 + row < p.M && (int)(bx * HPT) + hh < p.rope.Hq + 2 * p.rope.Hkv)
             rope_pre = rope_prefetch(m0 + row, (int)(bx * HPT) + hh, (tid & 7) * 8, p.rope);
     }
 
@@ -675,7 +745,6 @@ void qgemm_kernel(const GemmParams p) {
     // stores are done by WK times more lanes than if wave 0 kept the whole tile.  Register indices must
     // be compile-time constants, hence one instantiation of the tail per wk.
     constexpr int RN = 16 / WK;
-    const int S = gridDim.z;
     const int n = n0 + l31;
     const bool nvalid = n < p.N;
     float sw = 1.f, bias = 0.f;
@@ -712,7 +781,7 @@ void qgemm_kernel(const GemmParams p) {
             // reads) out of this kernel and lets K be cut as finely as the chip needs workgroups.
             // (int8 x int8: the slabs hold the int32 sums themselves, so the consumer adds integers exactly)
             if (!nvalid) return;
-            raw_t* dst = (raw_t*)p.partial_rm + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N + n;
+            raw_t* dst = (raw_t*)p.partial_rm + (size_t)slot * (size_t)p.M * (size_t)p.N + n;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -725,9 +794,14 @@ void qgemm_kernel(const GemmParams p) {
         }
         if (S > 1) {
             // split-K across workgroups: slab store, ticket, the last arriver sums the slabs in slice order
-            const unsigned tile = by * gridDim.x + bx;
-            raw_t* slab = (raw_t*)p.partial + ((size_t)tile * S) * (WN * MT * 16 * 64) + (size_t)wn * (MT * 16 * 64) + lane;
-            raw_t* mine = slab + (size_t)blockIdx.z * (WN * MT * 16 * 64);
+            const unsigned tile = tile_id;
+            // (a slab holds the tile as register PAIRS: pair q of a lane at [strip][q][lane], 8 bytes per access)
+            typedef unsigned long long u64;
+            u64* slab = (u64*)p.partial + (size_t)slab0 * (WN * MT * 8 * 64) + (size_t)wn * (MT * 8 * 64) + lane;
+            u64* mine = slab + (size_t)slot * (WN * MT * 8 * 64);
+            auto pack2 = [](raw_t lo, raw_t hi) -> u64 {
+                return ((u64)__builtin_bit_cast(unsigned, hi) << 32) | (u64)__builtin_bit_cast(unsigned, lo);
+            };
             // Partial tiles travel between workgroups (possibly on different XCDs, whose L2s are not
             // coherent with each other) as agent-scope relaxed atomics: write-through stores, cache-
             // bypassing loads.  Completed stores (vmcnt(0) + barrier) before the ticket and the ticket
@@ -735,8 +809,9 @@ void qgemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int rr = 0; rr < RN; ++rr)
-                    __hip_atomic_store(mine + (i * 16 + R0 + rr) * 64, acc[i][R0 + rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int rr = 0; rr < RN; rr += 2)
+                    __hip_atomic_store(mine + (i * 8 + (R0 + rr) / 2) * 64, pack2(acc[i][R0 + rr], acc[i][R0 + rr + 1]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                  // also: every wave is done with smem
             unsigned* flag = (unsigned*)smem;
@@ -748,18 +823,42 @@ void qgemm_kernel(const GemmParams p) {
             }
             __syncthreads();
             if (*flag == 0u) return;
+            // The last arriver still holds its own slice in registers and does not read it back.  The result must not
+            // depend on WHO is last, so the sum keeps the slice order ((0 + p0) + p1) + ...: the slices in front of
+            // this workgroup's are summed into temporaries, t + own equals own + t bit for bit (the sum they would
+            // give in either order), and the slices behind it are added to that.
+            // (two row fragments at a time: enough loads in flight per slice, and the temporaries stay few)
+            constexpr int FB = MT < 2 ? MT : 2;
+            static_assert(MT % FB == 0, "fragments in blocks");
+            auto fix_block = [&](auto i0c) {
+                constexpr int I0 = decltype(i0c)::value;
+                raw_t pre[FB][RN];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < FB; ++i)
 #pragma unroll
-                for (int rr = 0; rr < RN; ++rr) acc[i][R0 + rr] = 0;
-            for (int s = 0; s < S; ++s) {
-                raw_t* src = slab + (size_t)s * (WN * MT * 16 * 64);
+                    for (int rr = 0; rr < RN; ++rr) pre[i][rr] = 0;
+                auto add_slab = [&](int s2, auto to_pre) {
+                    const u64* src = slab + (size_t)s2 * (WN * MT * 8 * 64);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < FB; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < RN; ++rr)
-                        acc[i][R0 + rr] += __hip_atomic_load(src + (i * 16 + R0 + rr) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+                        for (int rr = 0; rr < RN; rr += 2) {
+                            const u64 v = __hip_atomic_load(src + ((I0 + i) * 8 + (R0 + rr) / 2) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const raw_t lo = __builtin_bit_cast(raw_t, (unsigned)v), hi = __builtin_bit_cast(raw_t, (unsigned)(v >> 32));
+                            if constexpr (decltype(to_pre)::value) { pre[i][rr] += lo; pre[i][rr + 1] += hi; }
+                            else { acc[I0 + i][R0 + rr] += lo; acc[I0 + i][R0 + rr + 1] += hi; }
+                        }
+                };
+                for (int s2 = 0; s2 < slot; ++s2) add_slab(s2, TrueT{});
+#pragma unroll
+                for (int i = 0; i < FB; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < RN; ++rr) acc[I0 + i][R0 + rr] = pre[i][rr] + acc[I0 + i][R0 + rr];
+                for (int s2 = slot + 1; s2 < S; ++s2) add_slab(s2, FalseT{});
+            };
+            fix_block(std::integral_constant<int, 0>{});
+            if constexpr (MT > 2) fix_block(std::integral_constant<int, 2>{});
+            if constexpr (MT > 4) { fix_block(std::integral_constant<int, 4>{}); fix_block(std::integral_constant<int, 6>{}); }
         }
 
         // epilogue: scale (+ bias), one hardware RTNE conversion, 2-byte store per element
@@ -823,7 +922,8 @@ void qgemm_kernel(const GemmParams p) {
                                 if (a > 0x7F80) a = 0;
 #pragma unroll
                                 for (int o = 16; o > 0; o >>= 1) a = max(a, __shfl_xor(a, o));
-                                if (l31 == 0)
+                                // (a tile wider than what is left of N: strips past the last one have no slot)
+                                if (l31 == 0 && (int)((bx * WN + wn) >> 1) < p.nparts_out)
                                     p.rowmax_out[(size_t)(m0 + rowc + 4 * lh) * p.nparts_out + ((bx * WN + wn) >> 1)] =
                                         bf16_bits_to_f32((unsigned short)a);
                             }
@@ -896,6 +996,8 @@ void qgemm_kernel(const GemmParams p) {
                 for (int idx = tid; idx < C::BM * HPT * 8; idx += C::NT) {
                     const int s8 = (idx & 7) * 8, hh = (idx >> 3) % HPT, row = (idx >> 3) / HPT;
                     if (m0 + row >= p.M) break;               // (rows ascend with idx; whole 8-lane groups leave together)
+                    // a 256-column tile over an odd number of heads: the last tile's second head does not exist
+                    if (head0 + hh >= p.rope.Hq + 2 * p.rope.Hkv) continue;
                     const unsigned short* src = img + row * C::ROPE_RS + hh * 128 + s8;
                     RopePre pre;
                     if constexpr (ROPE_EARLY) pre = rope_pre;      // (one pass: idx == tid, and the row was valid at entry)
@@ -937,6 +1039,8 @@ void qgemm_kernel(const GemmParams p) {
             case 7: if constexpr (WK > 4) tail(std::integral_constant<int, 7>{}); break;
         }
     }
+    if constexpr (SK) __syncthreads();                            // the next segment's staging reuses the tail's LDS
+    } while (SK && sk_u < sk_uend);
 }
 
 // The tile configurations that are built: {MT, WN, WK, CP, DB}
@@ -954,6 +1058,16 @@ struct TileCfg { int mt, wn, wk, cp, db; };
 #define QL_TILE_LIST_TALL(X) X(8, 4, 1, 4, true)
 // tiles also built with the qkv (q/k norm + RoPE + KV store) epilogue: 128- or 256-column tiles
 #define QL_TILE_LIST_ROPE(X) X(1, 4, 2, 16, false) X(1, 4, 1, 4, true) X(2, 4, 2, 4, true) X(2, 4, 1, 4, true) X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)
+
+// tiles also built with the stream-K schedule (the double-buffered tiles of 64+ rows or 128+ columns that the
+// mid-size problems - 64..512 rows on the larger models' shapes - want, and the streaming tiles of the small ones)
+#define QL_TILE_LIST_SK(X)                                                                           \
+    X(1, 1, 4, 4, true) X(1, 2, 4, 4, true) X(2, 2, 4, 4, true) X(2, 2, 2, 4, true)                  \
+    X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true) X(2, 4, 2, 4, true) X(4, 4, 2, 4, true) \
+    X(4, 8, 1, 2, true) X(4, 8, 1, 4, true)                                                          \
+    X(1, 1, 8, 4, false) X(1, 2, 4, 8, false) X(1, 4, 2, 16, false)
+#define QL_TILE_LIST_SK_TALL(X) X(8, 4, 1, 4, true)
+#define QL_TILE_LIST_SK_ROPE(X) X(1, 4, 1, 4, true) X(2, 4, 2, 4, true) X(2, 4, 1, 4, true) X(4, 8, 1, 2, true)
 
 // one translation unit per arithmetic variant instantiates these
 // The output projection (bf16 weights shared with the embedding table, vocabulary-sized N, M = sequences of a step)
@@ -984,6 +1098,26 @@ kern_t pick_kernel_impl(int mt, int wn, int wk, int cp, bool rope) {
     return nullptr;
 }
 
+// the weight-only kernels on the stream-K schedule (translation units of their own: ql_gemm_inst_sk_*.hip)
+template <bool FP8W, bool GROUP>
+kern_t pick_sk_impl(int mt, int wn, int wk, int cp, bool rope) {
+    if (rope) {
+#define QL_PICK(MT_, WN_, WK_, CP_, DB_) \
+        if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) \
+            return (kern_t)qgemm_kernel<ACT_BF16, FP8W, MT_, WN_, WK_, CP_, DB_, GROUP, true, false, false, false, true>;
+        QL_TILE_LIST_SK_ROPE(QL_PICK)
+#undef QL_PICK
+        return nullptr;
+    }
+#define QL_PICK(MT_, WN_, WK_, CP_, DB_) \
+    if (mt == MT_ && wn == WN_ && wk == WK_ && cp == CP_) \
+        return (kern_t)qgemm_kernel<ACT_BF16, FP8W, MT_, WN_, WK_, CP_, DB_, GROUP, false, false, false, false, true>;
+    QL_TILE_LIST_SK(QL_PICK)
+    if constexpr (!GROUP) { QL_TILE_LIST_SK_TALL(QL_PICK) }
+#undef QL_PICK
+    return nullptr;
+}
+
 // the W8A8 kernels with the activation quantization in their staging (x arrives as bf16 + partial row maxima)
 template <int ACT, bool FP8W>
 kern_t pick_dynq_impl(int mt, int wn, int wk, int cp) {
@@ -1010,6 +1144,10 @@ kern_t pick_i8_i8(int, int, int, int, bool rope = false);
 kern_t pick_fp8_fp8(int, int, int, int, bool rope = false);
 kern_t pick_head(int, int, int, int, bool amax);
 kern_t pick_i8_i8_dynq(int, int, int, int);
+kern_t pick_sk_bf16_i8_row(int, int, int, int, bool rope);
+kern_t pick_sk_bf16_i8_group(int, int, int, int, bool rope);
+kern_t pick_sk_bf16_fp8_row(int, int, int, int, bool rope);
+kern_t pick_sk_bf16_fp8_group(int, int, int, int, bool rope);
 kern_t pick_fp8_fp8_dynq(int, int, int, int);
 
 }  // namespace ql

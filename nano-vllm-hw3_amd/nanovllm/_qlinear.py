@@ -37,8 +37,9 @@ SIGNATURES = {
     "ql_gemm_w8a8": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_vp, _c_sz, _c_vp]),
     "ql_gemm_w8a16_silu": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
-                                    _c_int, _c_vp]),
-    "ql_gemm_w8a8_silu": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
+                                    _c_int, _c_vp, _c_sz, _c_vp]),
+    "ql_gemm_w8a8_silu": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz,
+                                   _c_vp]),
     "ql_gemm_partial_slices": (_c_int, [_c_i64, _c_i64, _c_i64, _c_int]),
     "ql_gemm_w8a16_partial": (_c_int, [_c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_int, _c_vp]),
     "ql_add_rmsnorm_partial": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp,
@@ -64,7 +65,8 @@ SIGNATURES = {
     "ql_gemm_w8a8_partial": (_c_int, [_c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_vp]),
     "ql_add_rmsnorm_partial_w8a8": (_c_int, [_c_int, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float,
                                              _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
-    "ql_gemm_w8a8_silu_rowmax": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ql_gemm_w8a8_silu_rowmax": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
+                                          _c_sz, _c_vp]),
     "ql_gemm_w8a8_dynq": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
                                    _c_sz, _c_vp]),
     "ql_lmhead_logits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),

@@ -53,13 +53,18 @@ def _add_rmsnorm_partial(ps, residual, weight, eps, quant_dtype=None):
             q.data_ptr() if q is not None else None, scale.data_ptr() if scale is not None else None, T, H,
             Q.stream_ptr(residual.device)))
         return (out, res_out) if quant_dtype is None else (q, scale, res_out)
-    assert quant_dtype is None, "weight-only partial sums feed a bf16 norm output"
     out = torch.empty_like(res_out)
     Q.check(Q.load().ql_add_rmsnorm_partial(ps.parts.data_ptr(), S, ps.granularity, ps.sw.data_ptr(),
                                             ps.bias.data_ptr() if ps.bias is not None else None, residual.data_ptr(),
                                             weight.data_ptr(), eps, out.data_ptr(), res_out.data_ptr(), T, H,
                                             Q.stream_ptr(residual.device)))
-    return out, res_out
+    if quant_dtype is None:
+        return out, res_out
+    # a weight-only linear in front of a W8A8 one (mixed per-module quantization): the bf16 norm output is
+    # quantized by its own launch, which is what the unfused pair computes
+    from nanovllm.utils.quantization import per_row_quant
+    q, scale = per_row_quant(out.reshape(T, H), quant_dtype)
+    return q, scale, res_out
 
 
 def add_rmsnorm_quant(x, residual, weight, eps, dtype):

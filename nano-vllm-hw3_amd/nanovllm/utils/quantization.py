@@ -153,9 +153,10 @@ def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False, out=None
     lib = Q.load()
     if silu:
         y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=x.device)
+        ws_ptr, ws_len = Q.workspace.get(x.device, lib.ql_gemm_workspace_bytes(M, N, K, granularity))
         Q.check(lib.ql_gemm_w8a16_silu(_wcode(qw, dtype), granularity, x2.data_ptr(), qw.data_ptr(), sw32.data_ptr(),
                                        bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
-                                       group_size or 0, Q.stream_ptr(x.device)))
+                                       group_size or 0, ws_ptr, ws_len, Q.stream_ptr(x.device)))
         return y.view(y_shape)
     if out is not None:
         assert out.shape == (M, N)
@@ -212,15 +213,17 @@ def w8a8_matmul(qx, sx, qw, sw, bias, dtype, y_shape=None, silu=False, out=None,
     assert silu or not return_rowmax
     if silu:
         y = torch.empty((M, N // 2), dtype=torch.bfloat16, device=qx.device)
+        ws_ptr, ws_len = Q.workspace.get(qx.device, lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW))
         if return_rowmax:
             rowmax = torch.empty((M, N // 64), dtype=torch.float32, device=qx.device)
             Q.check(lib.ql_gemm_w8a8_silu_rowmax(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(),
                                                  sw.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                 y.data_ptr(), rowmax.data_ptr(), M, N, K, Q.stream_ptr(qx.device)))
+                                                 y.data_ptr(), rowmax.data_ptr(), M, N, K, ws_ptr, ws_len,
+                                                 Q.stream_ptr(qx.device)))
             return (y if y_shape is None else y.view(y_shape)), rowmax
         Q.check(lib.ql_gemm_w8a8_silu(_wcode(qw, dtype), qx.data_ptr(), sx.data_ptr(), qw.data_ptr(), sw.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), M, N, K,
-                                      Q.stream_ptr(qx.device)))
+                                      ws_ptr, ws_len, Q.stream_ptr(qx.device)))
         return y if y_shape is None else y.view(y_shape)
     if out is not None:
         assert out.shape == (M, N)

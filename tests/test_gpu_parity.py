@@ -318,12 +318,15 @@ def test_tiled_weights_every_tile(NQ, tile):
 
 # ----------------------------------------------------------------------------- fused SiLU * mul epilogue
 @pytest.mark.parametrize("tile", [t for t in TILES if t[1] % 2 == 0])
-def test_fused_silu_epilogue_bit_identical(NQ, tile):
+@pytest.mark.parametrize("split", [1, 3])
+def test_fused_silu_epilogue_bit_identical(NQ, tile, split):
     """gate/up GEMM with the SiLU*mul epilogue on the strip-interleaved weight == the plain GEMM on the
     packed weight followed by the stand-alone SiLU*mul operator, bit for bit, for every arithmetic
-    variant and every tile that pairs column strips (M and N tails included)."""
+    variant and every tile that pairs column strips (M and N tails included); with K split across workgroups the
+    tile's last workgroup runs the gate/up exchange on the reduced tile (same slices on both routes)."""
     from nanovllm import _qlinear as Q, ops
     lib = Q.load()
+    Q.workspace.reserve("cuda", 64 << 20)
     M, I, K = 70, 160, 1152
     rng = np.random.default_rng(5)
     xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (2 * I, K), 0.05)
@@ -331,7 +334,7 @@ def test_fused_silu_epilogue_bit_identical(NQ, tile):
     bias = bf16_t(rand_bf16(rng, (2 * I,), 0.5))
     il = NQ.interleave_gate_up
     try:
-        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], 1) == 0
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], split) == 0
         for tdt in (torch.int8, torch.float8_e4m3fn):
             for b in (None, bias):
                 bi = None if b is None else il(b)
@@ -419,6 +422,28 @@ def test_qkv_rope_epilogue_bit_identical(NQ, tile, split):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+@pytest.mark.parametrize("tile", [(4, 8, 1, 2), (4, 8, 1, 4)])
+def test_qkv_rope_epilogue_odd_head_count(NQ, tile):
+    """An odd number of heads (Hq = 5, Hkv = 1: a Qwen3-14B rank under TP = 8) on the 256-column tiles, whose last
+    tile holds ONE head: the tile's second, non-existent head must be skipped (it used to be stored as a V head one
+    past the end, i.e. over the next token's V head 0 in v_out and in the cache).  Bit for bit against the unfused pair."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    M, Hq, Hkv, K = 150, 5, 1, 512
+    x, w, bias, qn, kn, cs, pos, slots = _rope_setup(M, Hq, Hkv, K, 9)
+    slots = torch.arange(M, device="cuda", dtype=torch.int32)          # adjacent slots: an overrun lands on a checked row
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], 1) == 0
+        for mod in (NQ.QLinear(torch.int8, w, None, weight_only=True), NQ.QLinear(torch.int8, w, bias)):
+            mod.tile()
+            for _ in range(3):                                          # (the overrun raced with the legitimate store)
+                a, b = _rope_both_ways(NQ, mod, x, qn, kn, cs, pos, slots, Hq, Hkv, True)
+                for ta, tb, nm in zip(a, b, ("q", "k", "v", "k_cache", "v_cache")):
+                    assert torch.equal(ta, tb), (nm, tile)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
 @pytest.mark.parametrize("M", [1, 16, 33, 130, 256, 700, 2048])
 def test_qkv_rope_full_size_own_tiles(NQ, M):
     """Qwen3-0.6B qkv shape with the library's own tile choice for each route.  int8 W8A8 accumulates exactly, so the
@@ -452,6 +477,144 @@ def test_qkv_rope_full_size_own_tiles(NQ, M):
             assert (ta == tb).float().mean() > 0.9
 
 
+# ----------------------------------------------------------------------------- stream-K schedule
+SK_TILES = [(1, 1, 4, 4), (1, 2, 4, 4), (2, 2, 4, 4), (2, 2, 2, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (2, 4, 2, 4),
+            (4, 4, 2, 4), (4, 8, 1, 2), (4, 8, 1, 4), (1, 1, 8, 4), (1, 2, 4, 8), (1, 4, 2, 16), (8, 4, 1, 4)]   # QL_TILE_LIST_SK*
+SK_ROPE_TILES = [(1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4), (4, 8, 1, 2)]                                       # QL_TILE_LIST_SK_ROPE
+
+
+@pytest.mark.parametrize("tile", SK_TILES)
+@pytest.mark.parametrize("G", [8, 24, 48, 208])
+def test_stream_k_schedule_every_tile(NQ, tile, G):
+    """The stream-K schedule (a 1-D grid of G workgroups sharing the (tile, chunk) units, forced with split = -G) on
+    every tile built for it: M, N tails, a ragged last chunk, workgroup ranges that start and end inside tiles, grids
+    with more workgroups than units (G = 208 on the large tiles) and with the row tiles walked side by side (G a
+    multiple of 8 x row tiles).  Per-row int8 / fp8 and per-group against the oracle, run-to-run bit-identical."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    Q.workspace.reserve("cuda", 128 << 20)
+    M, N, K = 150, 200, 1184
+    rng = np.random.default_rng(31)
+    xb, wb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05)
+    x = bf16_t(xb)
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], -G) == 0
+        plan = Q.plan_query(0, M, N, K)
+        kb = 32 * tile[3] * tile[2]
+        units = -(-M // (32 * tile[0])) * -(-N // (32 * tile[1])) * -(-K // kb)
+        assert plan == (tile[0], tile[1], tile[2], tile[3], -min(G, units)), plan     # (never more workgroups than units)
+        for dt in DTYPES:
+            qo, so = O.per_row_quant(wb, dt)
+            qw, sw = q_t(qo, dt), torch.from_numpy(so).cuda()
+            y = NQ.per_row_weight_only_matmul(x, qw, sw, None, TDT[dt])
+            assert_gemm_close(bits16(y), O.w8a16_rowscale_matmul(xb, qo, so, None, dt, return_f64=True),
+                              O.abs_product_sum(xb, O._decode_q(qo, dt) * so[:, None]), what=f"stream-K w8a16 {dt} {tile} G={G}")
+            for _ in range(2):
+                assert torch.equal(NQ.per_row_weight_only_matmul(x, NQ.tile_weight(qw), sw, None, TDT[dt]), y)
+            if tile[0] <= 4:
+                g = 32 if dt == "int8" else 128
+                qg, sg = O.per_group_quant(wb[:, :1152], g, dt)
+                yg = NQ.per_group_matmul(bf16_t(xb[:, :1152]), q_t(qg, dt), torch.from_numpy(sg).cuda(), None, g, TDT[dt])
+                deq = (O._decode_q(qg, dt).reshape(N, -1, g) * sg[..., None]).reshape(N, -1)
+                assert_gemm_close(bits16(yg), O.per_group_matmul(xb[:, :1152], qg, sg, None, g, dt, return_f64=True),
+                                  O.abs_product_sum(xb[:, :1152], deq), what=f"stream-K group {dt} {tile} G={G}")
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("tile", [t for t in SK_TILES if t[1] % 2 == 0])
+@pytest.mark.parametrize("G", [16, 40])
+def test_stream_k_silu_epilogue_bit_identical(NQ, tile, G):
+    """SiLU*mul epilogue under the stream-K schedule == plain GEMM (same tile, same schedule) + ql_silu_mul, bit for bit.
+    Under this schedule the places where a tile's K range is cut between workgroups depend on the tile's position, so
+    the f32 summation order of a column depends on the column tile it sits in: the unfused route runs on the SAME
+    strip-interleaved weight and its output columns are put back in [gate | up] order before ql_silu_mul."""
+    from nanovllm import _qlinear as Q, ops
+    lib = Q.load()
+    Q.workspace.reserve("cuda", 128 << 20)
+    M, I, K = 150, 160, 1152
+    rng = np.random.default_rng(6)
+    x, w = bf16_t(rand_bf16(rng, (M, K))), bf16_t(rand_bf16(rng, (2 * I, K), 0.05))
+    bias = bf16_t(rand_bf16(rng, (2 * I,), 0.5))
+    il = NQ.interleave_gate_up
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], -G) == 0
+        perm = il(torch.arange(2 * I, device="cuda"))          # interleaved position -> packed row
+
+        def unfused(y_il):
+            y = torch.empty_like(y_il)
+            y[:, perm] = y_il
+            return ops.silu_mul(y)
+        for tdt in (torch.int8, torch.float8_e4m3fn):
+            qw, sw = NQ.per_row_quant(w, tdt)
+            for b in (None, bias):
+                bi = None if b is None else il(b)
+                ref = unfused(NQ.per_row_weight_only_matmul(x, il(qw), il(sw), bi, tdt))
+                got = NQ.per_row_weight_only_matmul(x, il(qw), il(sw), bi, tdt, silu=True)
+                assert torch.equal(got, ref), (tdt, tile, G)
+                plain = ops.silu_mul(NQ.per_row_weight_only_matmul(x, qw, sw, b, tdt))       # (packed weight: other cuts)
+                assert (got == plain).float().mean() > 0.99
+            if tile[0] <= 4:
+                qg, sg = NQ.per_group_quant(w, 128, tdt)
+                assert torch.equal(NQ.per_group_matmul(x, il(qg), il(sg), None, 128, tdt, silu=True),
+                                   unfused(NQ.per_group_matmul(x, il(qg), il(sg), None, 128, tdt)))
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("tile", SK_ROPE_TILES)
+@pytest.mark.parametrize("G", [16, 40])
+def test_stream_k_qkv_rope_epilogue_bit_identical(NQ, tile, G):
+    """qkv epilogue under the stream-K schedule == plain GEMM (same tile, same schedule) + ql_qknorm_rope_store."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    Q.workspace.reserve("cuda", 128 << 20)
+    M, Hq, Hkv, K = 150, 3, 1, 1184
+    x, w, bias, qn, kn, cs, pos, slots = _rope_setup(M, Hq, Hkv, K, 13)
+    try:
+        assert lib.ql_gemm_force_config(tile[0], tile[1], tile[2], tile[3], -G) == 0
+        mods = [NQ.QLinear(torch.int8, w, bias, weight_only=True), NQ.QLinear(torch.float8_e4m3fn, w, None, weight_only=True)]
+        if tile[0] <= 4:
+            mods.append(NQ.QGroupLinear(torch.int8, w[:, :1152].contiguous(), None, 128))
+        for mi, mod in enumerate(mods):
+            mod.tile()
+            xx = x if mod.qw.shape[1] == K else x[:, :1152].contiguous()
+            a, b = _rope_both_ways(NQ, mod, xx, qn, kn, cs, pos, slots, Hq, Hkv, True)
+            for ta, tb, nm in zip(a, b, ("q", "k", "v", "k_cache", "v_cache")):
+                assert torch.equal(ta, tb), (mi, nm, tile, G)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("shape", [("4b gate_up", 19456, 2560), ("4b down", 2560, 9728), ("4b qkv", 6144, 2560)])
+@pytest.mark.parametrize("M", [48, 256, 300])
+def test_stream_k_full_size_sampled_rows(NQ, shape, M):
+    """The schedule at the sizes it is built for (Qwen3-4B layer shapes, 256 and 512 workgroups, g128): sampled output
+    rows against the exactly evaluated formula, determinism, and a tile-aligned grid (every workgroup whole tiles)."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    _, N, K = shape
+    Q.workspace.reserve("cuda", 512 << 20)
+    g = torch.Generator(device="cuda").manual_seed(N + M)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    qg, sg = NQ.per_group_quant(w, 128, torch.int8)
+    tw = NQ.tile_weight(qg)
+    rows = [0, M // 2, M - 1]
+    xb = bits16(x[rows])
+    deq = (qg.cpu().numpy().astype(np.float32).reshape(N, -1, 128) * sg.cpu().numpy()[..., None]).reshape(N, K)
+    ref = O.per_group_matmul(xb, qg.cpu().numpy(), sg.cpu().numpy(), None, 128, "int8", return_f64=True)
+    l1 = O.abs_product_sum(xb, deq)
+    try:
+        for tile, G in (((4, 8, 1, 2), 256), ((2, 4, 2, 4), 512), ((1, 2, 4, 4), 512), ((4, 4, 2, 4), 304)):
+            assert lib.ql_gemm_force_config(*tile, -G) == 0
+            y = NQ.per_group_matmul(x, tw, sg, None, 128, torch.int8)
+            assert_gemm_close(bits16(y[rows]), ref, l1, what=f"stream-K {shape[0]} M={M} {tile} G={G}")
+            assert torch.equal(NQ.per_group_matmul(x, tw, sg, None, 128, torch.int8), y)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
 @pytest.mark.parametrize("tile", [(1, 1, 8, 4), (1, 1, 4, 4), (1, 1, 4, 2), (1, 2, 4, 8), (2, 2, 4, 8), (2, 4, 2, 4)])
 @pytest.mark.parametrize("split", [1, 2, 5])
 def test_deferred_splitk_norm_bit_identical(NQ, tile, split):
@@ -482,6 +645,25 @@ def test_deferred_splitk_norm_bit_identical(NQ, tile, split):
             assert torch.equal(new_res, ref_res) and torch.equal(out, ref_out), (mi, tile, split)
     finally:
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+
+
+def test_weight_only_partial_sum_into_a_quantizing_norm(NQ):
+    """A weight-only o_proj / down_proj in front of a W8A8 linear (mixed per-module quantization): the norm that
+    finishes the deferred GEMM must also hand out the quantized activations, equal to norm -> per_row_quant."""
+    from nanovllm import ops
+    M, N, K = 48, 256, 3072
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda", dtype=torch.bfloat16, generator=g)
+    nw = torch.ones(N, device="cuda", dtype=torch.bfloat16)
+    mod = NQ.QLinear(torch.int8, w, None, weight_only=True).tile()
+    ps = NQ.w8a16_partial_matmul(mod, x)
+    out, new_res = ops.add_rmsnorm(ps, res, nw, 1e-6)
+    for dt in (torch.int8, torch.float8_e4m3fn):
+        q, s, r2 = ops.add_rmsnorm_quant(ps, res, nw, 1e-6, dt)
+        q_ref, s_ref = NQ.per_row_quant(out, dt)
+        assert torch.equal(r2, new_res) and torch.equal(s, s_ref) and torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
 
 
 @pytest.mark.parametrize("nk", [(1024, 2048), (1024, 3072), (2560, 9728), (4096, 1536)])
@@ -862,6 +1044,30 @@ def test_w8a8_mlp_without_a_quantization_launch(NQ, dt, M, tile):
     assert rm.shape == (M, 2 * I // 64)
     assert torch.equal(rm, y.float().abs().view(M, I // 32, 32).amax(-1))
     assert torch.equal(NQ.w8a8_dynq_matmul(y, rm, qd, sd, None, tdt), NQ.per_row_matmul(y, qd, sd, None, tdt))
+
+
+@pytest.mark.parametrize("tile,I", [((4, 4, 1, 4), 96), ((4, 8, 1, 4), 96), ((4, 8, 1, 4), 1216), (None, 1216)])
+def test_w8a8_silu_rowmax_tile_wider_than_the_columns_left(NQ, tile, I):
+    """Row maxima from the SiLU epilogue when the tile's width does not divide N (N = 192 on 128- and 256-column tiles,
+    N = 2432 = the Qwen3-4B gate/up shard under TP = 8 at prefill size): strips past the last one have no slot in
+    rowmax_out and must not be written (they used to land in the next row's first slot)."""
+    from nanovllm import _qlinear as Q
+    lib = Q.load()
+    M, H = 1100, 128
+    g = torch.Generator(device="cuda").manual_seed(I)
+    x = torch.randn(M, H, device="cuda", dtype=torch.bfloat16, generator=g)
+    wgu = (torch.randn(2 * I, H, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    qgu, sgu = NQ.per_row_quant(wgu, torch.int8)
+    qgu, sgu = NQ.interleave_gate_up(qgu), NQ.interleave_gate_up(sgu)
+    qx, sx = NQ.per_row_quant(x, torch.int8)
+    if tile:
+        assert lib.ql_gemm_force_config(*tile, 1) == 0
+    try:
+        for _ in range(3):
+            y, rm = NQ.w8a8_matmul(qx, sx, qgu, sgu, None, torch.int8, silu=True, return_rowmax=True)
+            assert torch.equal(rm, y.float().abs().view(M, I // 32, 32).amax(-1)), (tile, I)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
 @pytest.mark.parametrize("tile", [(1, 1, 8, 4), (1, 1, 4, 4), (1, 2, 4, 8), (2, 2, 4, 8), (2, 4, 2, 4)])

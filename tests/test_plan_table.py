@@ -41,7 +41,10 @@ def test_plan_set_rejects_what_cannot_run(lib):
     N, K = 4096, 1024
     assert lib.ql_gemm_plan_set(0, 1, 32, N, K, 3, 4, 1, 4, 1) == -1               # tile not built
     assert lib.ql_gemm_plan_set(Q.QL_PLAN_SILU, 1, 32, N, K, 1, 1, 8, 4, 1) == -1   # SiLU pairs two column strips
-    assert lib.ql_gemm_plan_set(Q.QL_PLAN_SILU, 1, 32, N, K, 1, 2, 4, 8, 2) == -1   # ... inside one workgroup: no split
+    assert lib.ql_gemm_plan_set(0, 1, 32, N, K, 1, 1, 8, 4, 0) == -1               # no slices at all
+    assert lib.ql_gemm_plan_set(0, 1, 32, N, K, 2, 2, 4, 8, -256) == -1            # stream-K: not on this tile ...
+    assert lib.ql_gemm_plan_set(Q.QL_PLAN_W8A8, 1, 32, N, K, 2, 4, 2, 4, -256) == -1   # ... nor for the W8A8 kernels
+    assert lib.ql_gemm_plan_set(Q.QL_PLAN_PARTIAL, 1, 32, N, K, 2, 4, 2, 4, -256) == -1   # ... nor the deferred form
     assert lib.ql_gemm_plan_set(Q.QL_PLAN_ROPE, 1, 32, N, K, 1, 1, 8, 4, 1) == -1   # heads need 128-column tiles
     assert lib.ql_gemm_plan_set(Q.QL_PLAN_GROUP, 1, 32, N, K, 8, 4, 1, 4, 1) == -1  # no 256-row tile with group scales
     assert lib.ql_gemm_plan_set(0, 1, 32, N, 1000, 1, 1, 8, 4, 1) == -1             # K % 32
@@ -139,3 +142,25 @@ def test_table_entry_changes_the_launch_not_the_result(lib, mode):
     for y in (y0, y1):
         assert ((y.double() - ref).abs() <= 2.0 ** -7 * ref.abs() + 2.0 ** -17 * l1 + 1e-30).all()
     assert not torch.equal(y0, y1) or True                       # (bits may or may not differ; both are in tolerance)
+
+
+def test_stream_k_and_sliced_silu_entries(lib):
+    """split_k = -G selects the stream-K schedule (G workgroups, clamped to the units the problem has); the SiLU form
+    may be cut into K slices (the tile's last workgroup runs the gate/up exchange); workspace sizing follows both, also
+    for an entry whose row range starts and ends off the 32-row grid."""
+    from nanovllm import _qlinear as Q
+    N, K = 19456, 2560
+    base = lib.ql_gemm_workspace_max_bytes(512, N, K, 0)
+    assert lib.ql_gemm_plan_set(Q.QL_PLAN_SILU, 129, 256, N, K, 4, 8, 1, 2, -256) == 0
+    assert Q.plan_query(Q.QL_PLAN_SILU, 200, N, K) == (4, 8, 1, 2, -256)
+    assert lib.ql_gemm_plan_set(Q.QL_PLAN_SILU, 40, 50, N, K, 1, 2, 4, 8, 4) == 0
+    assert Q.plan_query(Q.QL_PLAN_SILU, 45, N, K) == (1, 2, 4, 8, 3)        # (K = 2560: three 1024-k chunks, three slices)
+    assert Q.plan_query(Q.QL_PLAN_SILU, 51, N, K)[4] == 1
+    tile_bytes = 128 * 256 * 4
+    tiles = 2 * (N // 256)
+    assert lib.ql_gemm_workspace_bytes(200, N, K, 0) == 65536 + (256 + tiles) * tile_bytes
+    assert lib.ql_gemm_workspace_max_bytes(512, N, K, 0) >= max(base, 65536 + (256 + tiles) * tile_bytes)
+    # a grid larger than the problem's units is clamped: 1 x 2 tiles x 2 chunks of the 64 x 128 tile
+    assert lib.ql_gemm_plan_set(0, 1, 64, 256, 512, 2, 4, 2, 4, -512) == 0
+    assert Q.plan_query(0, 64, 256, 512) == (2, 4, 2, 4, -4)
+    lib.ql_gemm_plan_clear()

@@ -1,7 +1,19 @@
 """The allocation-free entry point ql_gemm_w8a16_noalloc against ql_gemm_w8a16 (same kernels, workspace inside the
-library): bit-identical outputs on two calls in a row, the second with a smaller input, through the C ABI."""
+library): bit-identical outputs on two calls in a row, the second with a smaller input, through the C ABI, and both
+against the CPU oracle.
+
+The allocation-free entry point plans with the heuristics only (its fixed scratch is sized for their splits), while
+ql_gemm_w8a16 consults the table of measured plans first; another tile or split changes the f32 summation order.  The
+reference call is therefore made with the plan table cleared (and the table is reloaded afterwards), so that both
+routes run the same plan whatever the shipped table holds."""
+import contextlib
+
+import numpy as np
 import pytest
 import torch
+
+from oracle import qlinear_oracle as O
+from tests.util import assert_gemm_close, bits16
 
 pytestmark = pytest.mark.gpu
 
@@ -26,10 +38,34 @@ def _run(lib, Q, fn_noalloc, x, qw, sw, bias, gran, group):
     return y
 
 
+@contextlib.contextmanager
+def heuristics_only(lib, Q):
+    """No plan-table entries while the block runs: every entry point plans with the built-in heuristics."""
+    lib.ql_gemm_plan_clear()
+    try:
+        yield
+    finally:
+        Q.load_plan_table(Q.PLAN_TABLE, replace=True)
+
+
+def _oracle_check(y, x, qw, sw, bias, gran, group, what):
+    xb, qn, sn = bits16(x), qw.cpu().numpy(), sw.cpu().numpy()
+    bb = None if bias is None else bits16(bias)
+    if gran == 0:       # QL_PER_ROW
+        ref = O.w8a16_rowscale_matmul(xb, qn, sn, bb, "int8", return_f64=True)
+        l1 = O.abs_product_sum(xb, qn.astype(np.float32) * sn[:, None])
+    else:
+        ref = O.per_group_matmul(xb, qn, sn, bb, group, "int8", return_f64=True)
+        deq = (qn.astype(np.float32).reshape(qn.shape[0], -1, group) * sn[..., None]).reshape(qn.shape)
+        l1 = O.abs_product_sum(xb, deq)
+    assert_gemm_close(bits16(y), ref, l1, what=what, double_round=(gran != 0 and bias is not None))
+
+
 def test_noalloc_matches_workspace_entry_point_twice():
     from nanovllm import _qlinear as Q
     from nanovllm.utils import quantization as NQ
     lib = Q.load()
+    assert Q.QL_PER_ROW == 0
     g = torch.Generator(device="cuda").manual_seed(0)
     # (M, N, K, granularity, group): split-K shapes first (down_proj of Qwen3-0.6B splits K three ways), the second
     # call of each pair is smaller in every dimension; then a per-group problem and one that does not split at all
@@ -44,10 +80,13 @@ def test_noalloc_matches_workspace_entry_point_twice():
         else:
             qw, sw = NQ.per_group_quant(w, group, torch.int8)
         for b in (None, bias):
-            ref = _run(lib, Q, False, x, qw, sw, b, gran, group)
+            with heuristics_only(lib, Q):
+                assert lib.ql_gemm_plan_count() == 0
+                ref = _run(lib, Q, False, x, qw, sw, b, gran, group)
             assert torch.isfinite(ref.float()).all()
             got = _run(lib, Q, True, x, qw, sw, b, gran, group)
             assert torch.equal(got, ref), (M, N, K, gran)
+            _oracle_check(got, x, qw, sw, b, gran, group, f"noalloc {M}x{N}x{K} gran {gran}")
             again = _run(lib, Q, True, x, qw, sw, b, gran, group)       # the scratch now holds this call's own leftovers
             assert torch.equal(again, ref), (M, N, K, gran, "second call")
 
@@ -59,7 +98,8 @@ def test_noalloc_allocates_nothing_and_is_capturable():
     M, N, K = 96, 1024, 3072
     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     qw, sw = NQ.per_row_quant((torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16), torch.int8)
-    ref = _run(lib, Q, False, x, qw, sw, None, Q.QL_PER_ROW, 0)
+    with heuristics_only(lib, Q):
+        ref = _run(lib, Q, False, x, qw, sw, None, Q.QL_PER_ROW, 0)
     y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     _run(lib, Q, True, x, qw, sw, None, Q.QL_PER_ROW, 0)             # first call on the device: outside capture
     free0 = torch.cuda.mem_get_info()[0]
@@ -80,7 +120,8 @@ def test_noalloc_rejects_oversized_problems():
     lib = Q.load()
     # Qwen3-4B down_proj at 4096 rows: 32 x 20 tiles x 3 slices x 128 KiB of slabs, beyond the 16 MiB array
     M, N, K = 4096, 2560, 9728
-    need = lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW)
+    with heuristics_only(lib, Q):                                     # (what the entry point itself plans with)
+        need = lib.ql_gemm_workspace_bytes(M, N, K, Q.QL_PER_ROW)
     if need <= NOALLOC_BYTES:
         pytest.skip(f"the plan for this shape needs only {need} bytes")
     x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)

@@ -42,6 +42,17 @@ TILES = BK.TILES
 ROPE_TILES = [(1, 4, 2, 16), (1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4)]
 PARTIAL_TILES = [(1, 1, 8, 4), (1, 1, 8, 8), (1, 2, 4, 8), (1, 2, 4, 4), (2, 2, 4, 8), (2, 2, 4, 4), (1, 4, 1, 4),
                  (1, 4, 2, 16), (2, 4, 1, 4), (2, 4, 2, 4), (1, 2, 4, 16)]
+# tiles built with the stream-K schedule (QL_TILE_LIST_SK* in csrc/ql_gemm_kernel.h) and the grid sizes tried on them:
+# one to four workgroups per CU (a tile's registers decide how many of them are resident at once)
+SK_TILES = [(1, 1, 4, 4), (1, 2, 4, 4), (2, 2, 4, 4), (2, 2, 2, 4), (1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (2, 4, 2, 4),
+            (4, 4, 2, 4), (4, 8, 1, 2), (4, 8, 1, 4), (1, 1, 8, 4), (1, 2, 4, 8), (1, 4, 2, 16), (8, 4, 1, 4)]
+SK_ROPE_TILES = [(1, 4, 1, 4), (2, 4, 2, 4), (2, 4, 1, 4), (4, 8, 1, 2)]
+
+
+def sk_grids(t):
+    return (256, 512) if t[1] * t[2] == 8 else (256, 512, 768, 1024)
+
+
 MS = [16, 64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]
 PREFILL_MS = [1024, 2048, 4096, 8192, 16384]
 # prefill sizes: the double-buffered tiles of 64 rows and more, never split (thousands of tiles fill the chip)
@@ -163,6 +174,8 @@ def main():
                 fn = lambda i: NQ.qkv_rope_matmul(mods[i], x, None, rows, nw, nw, 1e-6, Hq, Hkv, 128, kc, vc, slots, False)  # noqa: E731
             cands = [None] + [(t, s) for t in ROPE_TILES for s in (1, 2, 4) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and s <= max(1, K // (32 * t[3] * t[2]))]
+            if not w8a8:
+                cands += [(t, -g) for t in SK_ROPE_TILES for g in sk_grids(t) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))]
             if args.prefill:
                 cands = [None] + [(t, 1) for t in PREFILL_ROPE_TILES]
             res, top = tune_one(lib, fn, nc, cands, args.iters)
@@ -180,6 +193,13 @@ def main():
             cands = [None] + [(t, 1) for t in (PREFILL_TILES if args.prefill else TILES)
                               if t[1] % 2 == 0 and not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and not (args.mode == "group" and t[0] == 8)]
+            if not args.prefill:
+                # K split across workgroups (the tile's last workgroup runs the gate/up exchange), and the stream-K schedule
+                cands += [(t, sp) for t in TILES for sp in (2, 4) if t[1] % 2 == 0 and not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
+                          and not (args.mode == "group" and t[0] == 8) and sp <= max(1, K // (32 * t[3] * t[2]))]
+                if not w8a8:
+                    cands += [(t, -g) for t in SK_TILES for g in sk_grids(t) if t[1] % 2 == 0
+                              and not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32)) and not (args.mode == "group" and t[0] == 8)]
             res, top = tune_one(lib, fn, nc, cands, args.iters)
             record(gbit | Q.QL_PLAN_SILU, "gate_up", N, K, M, lo, hi, res, top)
         del mods
@@ -200,6 +220,9 @@ def main():
                 plain_fn = lambda i: ops.add_rmsnorm(mods[i](x), resid, nw, 1e-6)  # noqa: E731
             cands = [None] + [(t, s) for t in TILES for s in (1, 2, 4, 8) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
                               and not (args.mode == "group" and t[0] == 8) and s <= max(1, K // (32 * t[3] * t[2]))]
+            if not w8a8:
+                cands += [(t, -g) for t in SK_TILES for g in sk_grids(t) if not (t[0] > 1 and t[0] * 32 >= 2 * max(M, 32))
+                          and not (args.mode == "group" and t[0] == 8)]
             if args.prefill:
                 cands = [None] + [(t, 1) for t in PREFILL_TILES if not (args.mode == "group" and t[0] == 8)]
             res, top = tune_one(lib, plain_fn, nc, cands, args.iters)

@@ -117,6 +117,10 @@ def main():
                     if sp > max(1, K // kb):
                         continue
                     lib.ql_gemm_force_config(mt, wn, wk, cp, sp)
+                    # (a negative split asks for the stream-K schedule: only on the tiles built for it)
+                    form = 1 if args.mode == "group" else 8 if args.mode in ("w8a8", "w8a8fp8") else 0
+                    if sp < 0 and Q.plan_query(form, M, N, K)[4] != sp:
+                        continue
                 else:
                     lib.ql_gemm_force_config(0, 0, 0, 0, 0)
                 try:
