@@ -112,17 +112,26 @@ def _graph_time(fn, side):
     return best
 
 
-def measure_decode_gemm(llm, step_batches):
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0, "int8": 5000.0}    # dense peaks of the MI355X matrix cores
+
+
+def measure_decode_gemm(llm, step_batches, model_key="0.6b"):
     """Average duration of the decode GEMM launches with HIP events on the launch stream, over the
     (batch bucket, layer shape) mix the timed region actually ran; returns the roofline object.
 
-    The 112 linear launches of one decode step are issued exactly as the decode graph issues them: the qkv
+    The linear launches of one decode step (4 per layer) are issued exactly as the decode graph issues them: the qkv
     projection with its q/k norm + RoPE + KV-store epilogue, gate/up with the SiLU epilogue, o_proj / down_proj
-    with their split-K reduction deferred to the residual add + RMSNorm launch where the plan does that.  What the
-    deferral moves into the norm launches is charged to the GEMMs: the norms that finish a deferred GEMM are part of
-    the timed graph, and a second graph with the same number of plain norms is subtracted."""
+    with their split-K reduction deferred to the residual add + RMSNorm launch where the plan does that; W8A8 modules
+    take the quantized activations the preceding norm / attention launch hands them (down_proj quantizes its own
+    input, a launch that is part of the timed graph).  What the deferral moves into the norm launches is charged to the
+    GEMMs: the norms that finish a deferred GEMM are part of the timed graph, and a second graph with the same number
+    of plain norms is subtracted.
+
+    The bound of a launch is the larger of its algorithmic bytes / HBM peak and its flops / MFMA peak (the 200+ row
+    buckets of the weight-only kernels sit on the MFMA side of the ridge); `frac_of_roofline` = sum of those bounds /
+    measured time.  `bound` names the side that holds more of that sum, `achieved` / `peak` / `frac` are on that side."""
     from nanovllm import ops
-    from nanovllm.utils.quantization import PartialSum, QLinear, qkv_rope_matmul
+    from nanovllm.utils.quantization import PartialSum, QLinear, _QBase, per_row_quant, qkv_rope_matmul
     runner = llm.model_runner
     buckets = {}
     for bs in step_batches:
@@ -130,16 +139,21 @@ def measure_decode_gemm(llm, step_batches):
         buckets[g] = buckets.get(g, 0) + 1
     layers = runner.model.model.layers
     mods = [[l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj] for l in layers]
-    if not isinstance(mods[0][0], QLinear):
+    if not isinstance(mods[0][0], _QBase):
         return None
-    attn0 = layers[0].self_attn
+    w8a8 = isinstance(mods[0][0], QLinear) and not mods[0][0].weight_only
+    qdt = mods[0][0].dtype
+    group = getattr(mods[0][0], "group_size", 0) or 0
+    mfma_peak = MFMA_PEAK_TFLOPS["bf16"] if not w8a8 else MFMA_PEAK_TFLOPS["fp8" if qdt == torch.float8_e4m3fn else "int8"]
     hidden = mods[0][1].qw.shape[0]
     nw = torch.ones(hidden, device="cuda", dtype=torch.bfloat16)
-    tot_t = tot_b = tot_n = tot_plain = tot_raw = tot_rope = 0.0
+    tot_t = tot_b = tot_n = tot_plain = tot_raw = tot_rope = tot_f = tot_roof = roof_hbm = roof_mfma = 0.0
+    per_bucket = []
     side = torch.cuda.Stream()
     with torch.inference_mode():
         for M, cnt in sorted(buckets.items()):
             xs = [torch.randn(M, m.qw.shape[1], device="cuda", dtype=torch.bfloat16) for m in mods[0]]
+            qs = [per_row_quant(x, qdt) for x in xs] if w8a8 else None
             res = torch.randn(M, hidden, device="cuda", dtype=torch.bfloat16)
             pos = torch.randint(0, 2000, (M,), device="cuda")
             slots = torch.arange(M, device="cuda", dtype=torch.int32)
@@ -149,13 +163,20 @@ def measure_decode_gemm(llm, step_batches):
                 for li, m4 in enumerate(mods):
                     at = layers[li].self_attn
                     qkv_rope_matmul(m4[0], xs[0], pos, at.cos_sin, at.q_norm.weight, at.k_norm.weight, at.eps, at.num_heads,
-                                    at.num_kv_heads, at.head_dim, at.k_cache, at.v_cache, slots, want_kv=False)
+                                    at.num_kv_heads, at.head_dim, at.k_cache, at.v_cache, slots, want_kv=False,
+                                    quantized=qs[0] if w8a8 else None)
                     for k in (1, 3):
-                        y = m4[k].forward_partial(xs[k])
+                        if w8a8:      # o_proj: quantized by the attention merge launch; down_proj: its own launch
+                            y = m4[k].forward_partial_quantized(*(qs[1] if k == 1 else per_row_quant(xs[3], qdt)))
+                        else:
+                            y = m4[k].forward_partial(xs[k])
                         if isinstance(y, PartialSum) and with_norms:
                             ops.add_rmsnorm(y, res, nw, 1e-6)
                             deferred[0] += 1
-                    m4[2](xs[2])
+                    if w8a8:
+                        m4[2].forward_quantized(*qs[2])
+                    else:
+                        m4[2](xs[2])
 
             def norms():
                 for _ in range(deferred[0]):
@@ -178,33 +199,65 @@ def measure_decode_gemm(llm, step_batches):
             deferred[0] = 0
             t1 = _graph_time(gemms, side)
             t0 = _graph_time(norms, side) if deferred[0] else 0.0
-            tot_plain += _graph_time(plain, side) * cnt
-            tot_raw += _graph_time(lambda: gemms(False), side) * cnt
-            tot_rope += _graph_time(ropes, side) * cnt
-            nbytes = sum(gemm_bytes(M, m.qw.shape[0], m.qw.shape[1],
-                                    m.qw.shape[0] // 2 if getattr(m, "silu_fused", False) else None)
-                         for m4 in mods for m in m4)
+            if model_key == "0.6b":     # (the other accountings of the headline object; the larger models skip them)
+                tot_plain += _graph_time(plain, side) * cnt
+                tot_raw += _graph_time(lambda: gemms(False), side) * cnt
+                tot_rope += _graph_time(ropes, side) * cnt
+            nbytes = nflop = roof = 0.0
+            for m4 in mods:
+                for m in m4:
+                    N, K = m.qw.shape
+                    b = gemm_bytes(M, N, K, N // 2 if getattr(m, "silu_fused", False) else None)
+                    if group:
+                        b += 4 * N * (K // group) - 4 * N           # [N, K/g] group scales instead of [N] row scales
+                    if w8a8:
+                        b -= M * K                                  # 1-byte activations in
+                    f = 2.0 * M * N * K
+                    tb, tf = b / (HBM_PEAK_GBPS * 1e9), f / (mfma_peak * 1e12)
+                    nbytes += b
+                    nflop += f
+                    roof += max(tb, tf)
+                    if tb >= tf:
+                        roof_hbm += tb * cnt
+                    else:
+                        roof_mfma += tf * cnt
             nlaunch = sum(len(m4) for m4 in mods)
             tot_t += (t1 - t0) * cnt
             tot_b += nbytes * cnt
+            tot_f += nflop * cnt
+            tot_roof += roof * cnt
             tot_n += nlaunch * cnt
+            per_bucket.append({"rows": M, "steps": cnt, "us_per_launch": round((t1 - t0) / nlaunch * 1e6, 2),
+                               "frac_of_roofline": round(roof / (t1 - t0), 4)})
+            del xs, qs, res, qkv_out
     if tot_n == 0:
         return None
     avg_us = tot_t / tot_n * 1e6
-    achieved = tot_b / tot_t / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(mods[0], buckets),
-            "kernel": "ql::qgemm_kernel (decode W8A16 GEMM, all four layer shapes as the decode graph launches them, "
-                      "M = graph bucket)",
-            "avg_launch_us": round(avg_us, 2),
-            # the same launches without the norms that finish the deferred reductions (what a kernel trace shows
-            # for these kernels, plus the launch gap), their self-contained form (every launch with its own reduction and a separate RoPE operator), and
-            # the launches' cost net of the stand-alone RoPE operator their epilogue replaced
-            "avg_launch_us_gemm_launches_only": round(tot_raw / tot_n * 1e6, 2),
-            "avg_launch_us_self_contained_form": round(tot_plain / tot_n * 1e6, 2),
-            "avg_launch_us_net_of_replaced_rope_launch": round((tot_t - tot_rope) / tot_n * 1e6, 2),
-            "avg_algorithmic_bytes": int(tot_b / tot_n),
-            "launches_weighted": int(tot_n)}
+    hbm_side = roof_hbm >= roof_mfma
+    gbps, tflops = tot_b / tot_t / 1e9, tot_f / tot_t / 1e12
+    achieved, peak, unit = (gbps, HBM_PEAK_GBPS, "GB/s") if hbm_side else (tflops, mfma_peak, "TFLOP/s")
+    kind = "W8A8" if w8a8 else "W8A16"
+    out = {"bound": "hbm" if hbm_side else "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+           "frac": round(achieved / peak, 4),
+           "traffic": pmc_traffic(mods[0], buckets) if model_key == "0.6b" and not w8a8 and not group else None,
+           "kernel": f"ql::qgemm_kernel (decode {kind} GEMM, all four layer shapes as the decode graph launches them, "
+                     "M = graph bucket)",
+           "avg_launch_us": round(avg_us, 2),
+           # per launch: max(bytes / HBM peak, flops / MFMA peak) summed over the mix / measured time; and the two
+           # sides separately (what share of that bound sits on launches whose larger term is the byte one)
+           "frac_of_roofline": round(tot_roof / tot_t, 4),
+           "roofline_share_hbm_bound_launches": round(roof_hbm / (roof_hbm + roof_mfma), 3),
+           "achieved_GBps": round(gbps, 1), "achieved_TFLOPs": round(tflops, 1),
+           "avg_algorithmic_bytes": int(tot_b / tot_n), "avg_flop": int(tot_f / tot_n),
+           "launches_weighted": int(tot_n), "buckets": per_bucket}
+    if model_key == "0.6b":
+        # the same launches without the norms that finish the deferred reductions (what a kernel trace shows
+        # for these kernels, plus the launch gap), their self-contained form (every launch with its own reduction and a separate RoPE operator), and
+        # the launches' cost net of the stand-alone RoPE operator their epilogue replaced
+        out.update({"avg_launch_us_gemm_launches_only": round(tot_raw / tot_n * 1e6, 2),
+                    "avg_launch_us_self_contained_form": round(tot_plain / tot_n * 1e6, 2),
+                    "avg_launch_us_net_of_replaced_rope_launch": round((tot_t - tot_rope) / tot_n * 1e6, 2)})
+    return out
 
 
 def measure_prefill_gemm(llm, M=16384):
@@ -213,10 +266,10 @@ def measure_prefill_gemm(llm, M=16384):
     latency-bound decode legs, and the first ~10 ms of MFMA-bound work run at the clocks those left behind: a
     5-round measurement read 5-10 % low); achieved = 2*M*N*K flop / time against the dense bf16 MFMA peak (the W8A16
     kernel contracts on bf16 MFMA after widening the weights)."""
-    from nanovllm.utils.quantization import QLinear
+    from nanovllm.utils.quantization import _QBase
     l0 = llm.model_runner.model.model.layers[0]
     mods = [l0.self_attn.qkv_proj, l0.self_attn.o_proj, l0.mlp.gate_up_proj, l0.mlp.down_proj]
-    if not isinstance(mods[0], QLinear):
+    if not isinstance(mods[0], _QBase):
         return None
     with torch.inference_mode():
         xs = [torch.randn(M, m.qw.shape[1], device="cuda", dtype=torch.bfloat16) for m in mods]
@@ -323,6 +376,8 @@ def main():
     ap.add_argument("--dtype", default="int8", choices=["int8", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the FP8 W8A8 and Qwen3-4B g128 passes that follow the headline pass")
     ap.add_argument("--quant-lm-head", action="store_true", help="opt-in int8 LM head (not the reference's numerics)")
     ap.add_argument("--max-model-len", type=int, default=4096, help="4096 = the reference bench; other values are experiments")
     ap.add_argument("--model", default="0.6b", choices=sorted(MODELS),
@@ -351,95 +406,124 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from nanovllm import LLM, SamplingParams
-    model_dir = tempfile.mkdtemp(prefix=f"qwen3_06b_r{rank}_")
-    with open(os.path.join(model_dir, "config.json"), "w") as f:
-        json.dump(MODELS[args.model][1], f)
-    kw = dict(enforce_eager=False, max_model_len=args.max_model_len, load_format="dummy", tensor_parallel_size=world)
-    if args.quant != "bf16":
-        kw.update(quant_type=args.quant, linear_dtype=torch.int8 if args.dtype == "int8" else torch.float8_e4m3fn,
-                  group_size=128)
-    if args.quant_lm_head:
-        kw.update(quantize_lm_head=True)
-    decode_mode = "hipGraph decode"
-    llm, capture_error = None, None
-    try:
-        llm = LLM(model_dir, **kw)
-    except Exception as ex:  # noqa: BLE001
-        if world == 1:
-            raise
-        # Tensor-parallel ranks only: a collective that this RCCL build cannot capture into a hipGraph fails the
-        # capture on every rank alike; the curve is then measured with eager decode steps, and the line says so.
-        capture_error = type(ex).__name__
-        print(f"[rank {rank}] graph capture failed ({capture_error}: {ex}); falling back to eager decode",
-              file=sys.stderr, flush=True)
-    if llm is None:
-        # (outside the handler: the exception's traceback keeps the first engine - weights, KV cache - alive)
-        import gc
-        gc.collect()
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        kw["enforce_eager"] = True
-        decode_mode = f"EAGER decode (graph capture failed: {capture_error})"
-        llm = LLM(model_dir, **kw)
-
     prompts, max_tokens = workload()
     sps = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m) for m in max_tokens]
     total_tokens = sum(max_tokens)
-
-    # record the decode batch size of every step of one pass (for the roofline mix)
-    step_batches = []
-    orig_launch = llm.model_runner.launch
-
-    def logged_launch(seqs, is_prefill, prev=None):
-        if not is_prefill:
-            step_batches.append(len(seqs))
-        return orig_launch(seqs, is_prefill, prev=prev)
-    llm.model_runner.launch = logged_launch
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        # same shapes as the timed pass but one tenth of the decode length: warms graphs and allocator
-        llm.generate(prompts, [SamplingParams(ignore_eos=True, max_tokens=max(8, m // 10)) for m in max_tokens])
-    step_batches.clear()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        llm.generate(prompts, sps)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def run_config(model, quant, dtype, steps, warmup):
+        """Build the engine for one configuration, run `warmup` short passes and `steps` timed passes of the workload;
+        returns (llm, seconds per pass, decode batch sizes of one pass, decode mode, captured?)."""
+        model_dir = tempfile.mkdtemp(prefix=f"qwen3_{model}_r{rank}_")
+        with open(os.path.join(model_dir, "config.json"), "w") as f:
+            json.dump(MODELS[model][1], f)
+        kw = dict(enforce_eager=False, max_model_len=args.max_model_len, load_format="dummy", tensor_parallel_size=world)
+        if quant != "bf16":
+            kw.update(quant_type=quant, linear_dtype=torch.int8 if dtype == "int8" else torch.float8_e4m3fn, group_size=128)
+        if args.quant_lm_head:
+            kw.update(quantize_lm_head=True)
+        decode_mode, graph = "hipGraph decode", True
+        llm, capture_error = None, None
+        try:
+            llm = LLM(model_dir, **kw)
+        except Exception as ex:  # noqa: BLE001
+            if world == 1:
+                raise
+            # Tensor-parallel ranks only: a collective that this RCCL build cannot capture into a hipGraph fails the
+            # capture on every rank alike; the curve is then measured with eager decode steps, and the line says so.
+            capture_error = type(ex).__name__
+            print(f"[rank {rank}] graph capture failed ({capture_error}: {ex}); falling back to eager decode",
+                  file=sys.stderr, flush=True)
+        if llm is None:
+            # (outside the handler: the exception's traceback keeps the first engine - weights, KV cache - alive)
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            kw["enforce_eager"] = True
+            decode_mode, graph = f"EAGER decode (graph capture failed: {capture_error})", False
+            llm = LLM(model_dir, **kw)
+        # record the decode batch size of every step of one pass (for the roofline mix)
+        step_batches = []
+        orig_launch = llm.model_runner.launch
 
+        def logged_launch(seqs, is_prefill, prev=None):
+            if not is_prefill:
+                step_batches.append(len(seqs))
+            return orig_launch(seqs, is_prefill, prev=prev)
+        llm.model_runner.launch = logged_launch
+        for _ in range(warmup):
+            # same shapes as the timed pass but one tenth of the decode length: warms graphs and allocator
+            llm.generate(prompts, [SamplingParams(ignore_eos=True, max_tokens=max(8, m // 10)) for m in max_tokens])
+        step_batches.clear()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            llm.generate(prompts, sps)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return llm, dt / steps, step_batches[: len(step_batches) // max(steps, 1)], decode_mode, graph
+
+    def workload_text(model_name, quant, dtype, decode_mode):
+        return ("reference bench.py: 256 seqs, prompts 100-1024 random tokens, 100-1024 new tokens "
+                f"(133,966 output tokens), {model_name} random-init, "
+                f"quant={quant}/{dtype if quant != 'bf16' else 'none'}, {decode_mode}")
+
+    def arith(quant, dtype):
+        return "bf16" if quant in ("bf16", "per_row_weight_only", "per_group", "per_tensor") else dtype
+
+    llm, spp, batches, decode_mode, graph = run_config(args.model, args.quant, args.dtype, args.steps, args.warmup)
     roof = roof_prefill = roof_attn = None
     # (one GPU only: under tensor parallelism the row-parallel modules' forward contains a collective, which one
     # rank must not issue alone)
     model_name = MODELS[args.model][0]
-    if rank == 0 and world == 1 and not args.no_roofline and args.quant != "bf16" and args.model == "0.6b":
-        roof = measure_decode_gemm(llm, step_batches[: len(step_batches) // max(args.steps, 1)])
-        roof_prefill = measure_prefill_gemm(llm)
-        roof_attn = measure_decode_attention(llm)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_roofline and args.quant != "bf16":
+        roof = measure_decode_gemm(llm, batches, args.model)
+        if args.model == "0.6b":
+            roof_prefill = measure_prefill_gemm(llm)
+            roof_attn = measure_decode_attention(llm)
+    line = None
     if rank == 0:
-        dtype = "bf16" if args.quant in ("bf16", "per_row_weight_only", "per_group", "per_tensor") else args.dtype
         line = {
-            "metric": f"tokens/s {model_name} INT8, 256 seqs (bench.py)", "value": round(args.steps * total_tokens / dt, 1),
+            "metric": f"tokens/s {model_name} INT8, 256 seqs (bench.py)", "value": round(total_tokens / spp, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "reference bench.py: 256 seqs, prompts 100-1024 random tokens, 100-1024 new tokens "
-                                   f"(133,966 output tokens), {model_name} random-init, "
-                                   f"quant={args.quant}/{args.dtype if args.quant != 'bf16' else 'none'}, {decode_mode}",
-                       "parallelism": f"tp{world}", "decode_steps": len(step_batches) // max(args.steps, 1)},
-            "roofline": roof, "roofline_prefill": roof_prefill, "roofline_attention": roof_attn, "cpu_baseline": cpu,
+            "ms_per_step": round(spp * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": arith(args.quant, args.dtype),
+            "data": "synthetic", "graph": graph,
+            "config": {"workload": workload_text(model_name, args.quant, args.dtype, decode_mode),
+                       "parallelism": f"tp{world}", "decode_steps": len(batches)},
+            "roofline": roof, "roofline_prefill": roof_prefill, "roofline_attention": roof_attn,
         }
+
+    # BASELINE's other single-GPU configurations on the same workload, one timed pass each after the headline's:
+    # Qwen3-0.6B FP8-e4m3 weights + activations on the fp8 MFMA, and Qwen3-4B INT8 g128 weight-only
+    extra = []
+    headline = args.model == "0.6b" and args.quant == "per_row_weight_only" and args.dtype == "int8"
+    if world == 1 and headline and not args.no_extra_configs:
+        import gc
+        for key, quant, dtype, label in (("0.6b", "per_row", "fp8", "Qwen3-0.6B FP8-e4m3 weight+activation (W8A8), TP=1"),
+                                         ("4b", "per_group", "int8", "Qwen3-4B INT8 group-size-128 weight-only (W8A16-g128), TP=1")):
+            del llm
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            llm, spp2, batches2, mode2, graph2 = run_config(key, quant, dtype, 1, 1)
+            r2 = None if args.no_roofline else measure_decode_gemm(llm, batches2, key)
+            extra.append({"config": label, "workload": workload_text(MODELS[key][0], quant, dtype, mode2),
+                          "value": round(total_tokens / spp2, 1), "unit": "tokens/s", "steps": 1, "warmup": 1,
+                          "ms_per_step": round(spp2 * 1e3, 2), "dtype": arith(quant, dtype), "graph": graph2,
+                          "decode_steps": len(batches2), "roofline": r2})
+    if rank == 0:
+        line["configs"] = extra
+        line["cpu_baseline"] = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

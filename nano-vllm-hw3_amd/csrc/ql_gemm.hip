@@ -731,7 +731,9 @@ int ql_gemm_w8a8_dynq(int dtype, const void* x, const float* rowmax_part, int np
 // row tiles run side by side on one XCD.  Every workgroup runs the whole K.  Measured with tools/bench_lmhead.py.
 static Plan make_plan_head(int64_t M, int64_t V, int64_t K) {
     Plan pl;
-    int mt = M <= 32 ? 1 : M <= 64 ? 2 : M <= 128 ? 4 : M <= 256 ? 8 : 4, wn = M <= 128 ? 4 : 8, wk = 1, cp = (M > 128 && M <= 256) ? 2 : 4;
+    // (129..256 rows: one row tile of as many 32-row fragments as the rows fill, 5..8)
+    int mt = M <= 32 ? 1 : M <= 64 ? 2 : M <= 128 ? 4 : M <= 256 ? (int)((M + 31) / 32) : 4, wn = M <= 128 ? 4 : 8, wk = 1,
+        cp = (M > 224 && M <= 256) ? 2 : 4;
     pl.pair_rows = true;
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && pick_head(f_mt, f_wn, f_wk, f_cp, false)) {
         mt = f_mt; wn = f_wn; wk = f_wk; cp = f_cp;

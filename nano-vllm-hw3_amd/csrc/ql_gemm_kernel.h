@@ -828,8 +828,7 @@ void qgemm_kernel(const GemmParams p) {
             // this workgroup's are summed into temporaries, t + own equals own + t bit for bit (the sum they would
             // give in either order), and the slices behind it are added to that.
             // (two row fragments at a time: enough loads in flight per slice, and the temporaries stay few)
-            constexpr int FB = MT < 2 ? MT : 2;
-            static_assert(MT % FB == 0, "fragments in blocks");
+            constexpr int FB = (MT % 2 == 0) ? 2 : 1;
             auto fix_block = [&](auto i0c) {
                 constexpr int I0 = decltype(i0c)::value;
                 raw_t pre[FB][RN];
@@ -856,9 +855,14 @@ void qgemm_kernel(const GemmParams p) {
                     for (int rr = 0; rr < RN; ++rr) acc[I0 + i][R0 + rr] = pre[i][rr] + acc[I0 + i][R0 + rr];
                 for (int s2 = slot + 1; s2 < S; ++s2) add_slab(s2, FalseT{});
             };
-            fix_block(std::integral_constant<int, 0>{});
-            if constexpr (MT > 2) fix_block(std::integral_constant<int, 2>{});
-            if constexpr (MT > 4) { fix_block(std::integral_constant<int, 4>{}); fix_block(std::integral_constant<int, 6>{}); }
+            auto all_blocks = [&](auto self, auto i0c) {
+                constexpr int I0 = decltype(i0c)::value;
+                if constexpr (I0 < MT) {
+                    fix_block(i0c);
+                    self(self, std::integral_constant<int, I0 + FB>{});
+                }
+            };
+            all_blocks(all_blocks, std::integral_constant<int, 0>{});
         }
 
         // epilogue: scale (+ bias), one hardware RTNE conversion, 2-byte store per element
@@ -1071,7 +1075,9 @@ struct TileCfg { int mt, wn, wk, cp, db; };
 
 // one translation unit per arithmetic variant instantiates these
 // The output projection (bf16 weights shared with the embedding table, vocabulary-sized N, M = sequences of a step)
-#define QL_TILE_LIST_HEAD(X) X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true) X(4, 8, 1, 4, true) X(8, 8, 1, 2, true)
+// (129..224 rows: 160-, 192- and 224-row tiles, so that a step's sequences cost the MFMAs of the row fragments they fill)
+#define QL_TILE_LIST_HEAD(X) X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true) X(4, 8, 1, 4, true) X(8, 8, 1, 2, true) \
+    X(5, 8, 1, 4, true) X(6, 8, 1, 4, true) X(7, 8, 1, 4, true)
 template <bool AMAX>
 kern_t pick_head_impl(int mt, int wn, int wk, int cp) {
 #define QL_PICK_HEAD(MT_, WN_, WK_, CP_, DB_) \

@@ -58,6 +58,9 @@ def _oracle_check(y, x, qw, sw, bias, gran, group, what):
         ref = O.per_group_matmul(xb, qn, sn, bb, group, "int8", return_f64=True)
         deq = (qn.astype(np.float32).reshape(qn.shape[0], -1, group) * sn[..., None]).reshape(qn.shape)
         l1 = O.abs_product_sum(xb, deq)
+    if bb is not None:                                               # (the f64 forms return the sum before the bias)
+        ref = ref + O.bf16_to_f32(bb).astype(np.float64)[None, :]
+        l1 = l1 + np.abs(O.bf16_to_f32(bb)).astype(np.float64)[None, :] * 2.0 ** 10   # (half an ulp of the bias itself)
     assert_gemm_close(bits16(y), ref, l1, what=what, double_round=(gran != 0 and bias is not None))
 
 

@@ -15,14 +15,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from nanovllm import _qlinear as Q, ops  # noqa: E402
 import bench_kernels as BK  # noqa: E402
 
-TILES = [(1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (4, 8, 1, 4), (8, 8, 1, 2)]
+TILES = [(1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (4, 8, 1, 4), (5, 8, 1, 4), (6, 8, 1, 4), (7, 8, 1, 4), (8, 8, 1, 2)]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--v", type=int, default=151936)
     ap.add_argument("--k", type=int, default=1024)
-    ap.add_argument("--ms", default="1,16,64,128,192,256")
+    ap.add_argument("--ms", default="1,16,64,128,130,160,192,224,256")
     ap.add_argument("--sweep", action="store_true")
     a = ap.parse_args()
     lib = Q.load()
