@@ -284,7 +284,22 @@ def measure_prefill_gemm(llm, M=16384):
                 m(x)
         e.record()
         torch.cuda.synchronize()
-    t = s.elapsed_time(e) * 1e-3 / 20
+        t = s.elapsed_time(e) * 1e-3 / 20
+        # the same-box ceiling this figure is read against: the vendor library's bf16 x bf16 GEMM (F.linear ->
+        # hipBLASLt) at the same four shapes and row count, same warm-up, no dequantization and no epilogue
+        ws = [(torch.randn(m.qw.shape[0], m.qw.shape[1], device="cuda") * 0.02).to(torch.bfloat16) for m in mods]
+        for _ in range(40):
+            for x, w in zip(xs, ws):
+                torch.nn.functional.linear(x, w)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(20):
+            for x, w in zip(xs, ws):
+                torch.nn.functional.linear(x, w)
+        e.record()
+        torch.cuda.synchronize()
+        t_lib = s.elapsed_time(e) * 1e-3 / 20
+        del ws
     flop = sum(2.0 * M * m.qw.shape[0] * m.qw.shape[1] for m in mods)
     tf = flop / t / 1e12
     # the W8A16 kernels contract on bf16 MFMA (2.5 PFLOP/s dense); the fp8 W8A8 kernel on the K = 64 block-scaled fp8
@@ -293,7 +308,8 @@ def measure_prefill_gemm(llm, M=16384):
     peak = 5000.0 if (w8a8 and mods[0].dtype == torch.float8_e4m3fn) else 2500.0
     form = "W8A8, activation quantization launch included" if w8a8 else "W8A16"
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-            "traffic": None, "kernel": f"ql::qgemm_kernel (prefill {form} GEMM, four layer shapes, M = {M})"}
+            "traffic": None, "kernel": f"ql::qgemm_kernel (prefill {form} GEMM, four layer shapes, M = {M})",
+            "hipblaslt_bf16_tflops": round(flop / t_lib / 1e12, 1), "vs_hipblaslt_bf16": round(t_lib / t, 3)}
 
 
 def measure_decode_attention(llm):

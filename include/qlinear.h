@@ -210,6 +210,37 @@ int ql_gemm_w8a8_rope(int dtype, const void* qx, const float* sx, const void* qw
                       void* k_out, void* v_out, void* k_cache, void* v_cache, const int* slot_mapping, int Hq,
                       int Hkv, int head_dim, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- row-parallel all-reduce over peer-mapped buffers (one node, up to 8 ranks) ------------------------
+ * RowParallelLinear.forward under tensor parallelism (nanovllm/layers/linear.py:149-153: F.linear on the K shard,
+ * then dist.all_reduce(y)) followed by the residual add + RMSNorm that consumes every o_proj / down_proj output
+ * (Qwen3DecoderLayer.forward, nanovllm/models/qwen3.py:153-162; RMSNorm.add_rms_forward, layernorm.py:28-40), in ONE
+ * launch and without the collective library: each rank pushes its bf16 partial rows into a slot of every peer's
+ * buffer, raises a per-row flag there, waits (bounded) for its peers' flags and sums the `world` partials in rank
+ * order in f32 from local memory:  y = bf16(sum_r partial_r)  - identical bits on every rank and on every replay -
+ * then exactly ql_add_rmsnorm(y, residual, weight).  weight == NULL: the plain all-reduce, y_out only.
+ *
+ * Set-up, once per process and communicator: ql_comm_alloc a buffer of ql_comm_buffer_bytes(world, max_rows, hidden)
+ * (zero-filled; device memory other agents may write), ql_comm_export its 64-byte handle, exchange the handles
+ * through any channel (the process group that already exists), ql_comm_import every peer's, and pass the `world`
+ * device pointers (own buffer at index rank) to every call.  Calls of one communicator must be issued in the same
+ * order on every rank and on one stream per rank; the sequence number lives in the buffer and is advanced by the
+ * launches themselves, so calls captured into a hipGraph replay correctly.  T <= max_rows (decode-sized messages;
+ * larger ones belong to the collective library).  spin_limit = polls a wait may make before it gives up (0: a few
+ * seconds' worth): a peer that never arrives makes the result wrong, never hangs the device; ql_comm_status
+ * (synchronous) returns how many waits have timed out since allocation. */
+#define QL_COMM_HANDLE_BYTES 64
+size_t ql_comm_buffer_bytes(int world, int64_t max_rows, int64_t hidden);
+int ql_comm_alloc(size_t bytes, void** buf);
+int ql_comm_free(void* buf);
+int ql_comm_export(void* buf, void* handle64);
+int ql_comm_import(const void* handle64, void** peer_buf);
+int ql_comm_unimport(void* peer_buf);
+int ql_comm_status(const void* buf, unsigned* epoch, unsigned* timeouts);
+int ql_allreduce_add_rmsnorm(int rank, int world, void* const* bufs, int64_t max_rows, int64_t hidden,
+                             const void* x_partial_bf16, const void* residual_bf16, const void* weight_bf16, float eps,
+                             void* y_out_bf16, void* out_bf16, void* residual_out_bf16, int64_t T, unsigned spin_limit,
+                             void* stream);
+
 /* Tuning hook for benchmarks/tests: force the tile configuration of the next GEMM calls made by
  * this thread.  mt = 32-row fragments per wave (1,2,4,8), wn x wk = how the block's 4 waves split
  * N and K ((4,1),(2,2),(1,4)), cp = 32-k steps a wave loads per chunk (2,4,8), split_k = K slices

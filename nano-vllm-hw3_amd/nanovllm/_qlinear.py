@@ -69,6 +69,15 @@ SIGNATURES = {
                                           _c_sz, _c_vp]),
     "ql_gemm_w8a8_dynq": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
                                    _c_sz, _c_vp]),
+    "ql_comm_buffer_bytes": (_c_sz, [_c_int, _c_i64, _c_i64]),
+    "ql_comm_alloc": (_c_int, [_c_sz, ctypes.POINTER(_c_vp)]),
+    "ql_comm_free": (_c_int, [_c_vp]),
+    "ql_comm_export": (_c_int, [_c_vp, _c_vp]),
+    "ql_comm_import": (_c_int, [_c_vp, ctypes.POINTER(_c_vp)]),
+    "ql_comm_unimport": (_c_int, [_c_vp]),
+    "ql_comm_status": (_c_int, [_c_vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
+    "ql_allreduce_add_rmsnorm": (_c_int, [_c_int, _c_int, ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_vp, _c_vp, _c_vp,
+                                          ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_uint, _c_vp]),
     "ql_lmhead_logits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ql_lmhead_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ql_lmhead_argmax": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),

@@ -15,6 +15,8 @@ def add_rmsnorm(x, residual, weight, eps):
     output whose split-K reduction and epilogue this launch performs)."""
     if hasattr(x, "parts"):
         return _add_rmsnorm_partial(x, residual, weight, eps)
+    if hasattr(x, "tp_partial"):       # a row-parallel shard's partial sum: all-reduce + this norm in one launch
+        return x.finish(residual, weight, eps)
     if not x.is_cuda:
         return cpu_ops.add_rmsnorm(x, residual, weight, eps)
     Q.require_cuda(x, BF16, "x")
@@ -72,6 +74,11 @@ def add_rmsnorm_quant(x, residual, weight, eps, dtype):
     (q, scale) bit-identical to per_row_quant(add_rmsnorm(...)[0], dtype).  x may be a W8A8 PartialSum."""
     if hasattr(x, "parts"):
         return _add_rmsnorm_partial(x, residual, weight, eps, quant_dtype=dtype)
+    if hasattr(x, "tp_partial"):
+        from nanovllm.utils.quantization import per_row_quant
+        out, res_out = x.finish(residual, weight, eps)
+        q, scale = per_row_quant(out, dtype)
+        return q, scale, res_out
     Q.require_cuda(x, BF16, "x")
     H = x.shape[-1]
     T = x.numel() // H

@@ -470,6 +470,9 @@ class _QBase(torch.nn.Module):
         the norm launch finishes; otherwise the plain output."""
         weight_only = not isinstance(self, QLinear) or self.weight_only
         m = x.numel() // x.shape[-1]
+        tpp = self._tp_partial(x)
+        if tpp is not None:
+            return tpp
         if not weight_only and x.dim() == 2 and x.is_cuda:
             # W8A8: quantize the activations (their own launch), then the deferred form where it pays
             return self.forward_partial_quantized(*per_row_quant(x.contiguous(), self.dtype))
@@ -480,7 +483,27 @@ class _QBase(torch.nn.Module):
                 return w8a16_partial_matmul(self, x)
         return self(x)
 
+    _defer_reduce = False
+
+    def _tp_partial(self, x, run=None):
+        """A row-parallel shard under TP with a decode-sized input and the one-shot all-reduce switched on
+        (layers/comm.py): the shard's own GEMM output, its all-reduce left to the norm launch behind it."""
+        if not (self.tp_dim == 1 and self.tp_size > 1 and x.is_cuda and x.dim() == 2):
+            return None
+        from nanovllm.layers import comm
+        c = comm.communicator(self.qw.shape[0], x.device)
+        if c is None or not (0 < x.shape[0] <= c.max_rows):
+            return None
+        self._defer_reduce = True
+        try:
+            y = self(x) if run is None else run()
+        finally:
+            self._defer_reduce = False
+        return comm.TPPartial(y, c)
+
     def _finish(self, y):
+        if self._defer_reduce:
+            return y
         if self.tp_dim == 1 and self.tp_size > 1:
             from nanovllm.layers.linear import tp_all_reduce
             y = tp_all_reduce(y)
@@ -562,6 +585,9 @@ class QLinear(_QBase):
         ops.add_rmsnorm_quant: at decode sizes, without a tensor-parallel all-reduce in between and when the plan has
         K slices to defer, a PartialSum that the norm launch finishes; otherwise the plain output."""
         m = qx.shape[0]
+        tpp = self._tp_partial(qx, run=lambda: self.forward_quantized(qx, sx))
+        if tpp is not None:
+            return tpp
         if (DEFER_SPLITK and not self.weight_only and not self.silu_fused and not (self.tp_dim == 1 and self.tp_size > 1)
                 and 0 < m <= self.PARTIAL_MAX_ROWS
                 and Q.load().ql_gemm_partial_slices(m, self.qw.shape[0], self.qw.shape[1], Q.QL_PER_ROW) > 1):

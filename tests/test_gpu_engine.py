@@ -727,7 +727,11 @@ def _tp_worker(rank, world, port, model_dir, out_path):
     from nanovllm import LLM, SamplingParams
     from nanovllm.models.qwen3 import AttnContext, set_context
     res = {}
-    for name, kw in (("bf16", {}), ("w8a16", dict(quant_type="per_row_weight_only", linear_dtype=torch.int8))):
+    for name, kw in (("bf16", {}), ("w8a16", dict(quant_type="per_row_weight_only", linear_dtype=torch.int8)),
+                     ("w8a16_oneshot", dict(quant_type="per_row_weight_only", linear_dtype=torch.int8))):
+        # the third pass: row-parallel partial sums all-reduced by the one-shot kernel over peer-mapped buffers, inside
+        # the residual add + RMSNorm launch (nanovllm/layers/comm.py), instead of the process group's all-reduce
+        os.environ["NANOVLLM_ONESHOT_AR"] = "1" if name.endswith("oneshot") else "0"
         llm = LLM(model_dir, load_format="dummy", enforce_eager=True, max_model_len=512, max_num_seqs=16,
                   tensor_parallel_size=world, **kw)
         out = llm.generate(_prompts(), SamplingParams(max_tokens=6, ignore_eos=True))
@@ -748,6 +752,9 @@ def _tp_worker(rank, world, port, model_dir, out_path):
         with torch.inference_mode():
             assert head.fused_sampler(xg)
             res[name]["head_equal"] = bool(torch.equal(head.greedy_tokens(xg), ops.lm_head_argmax(xg, torch.cat(parts).cuda())))
+        if name.endswith("oneshot"):
+            from nanovllm.layers import comm
+            res[name]["comm"] = comm.statuses()
         print(f"[tp worker {rank}] {name} done", flush=True)
     if rank == 0:
         torch.save(res, out_path)
@@ -789,6 +796,12 @@ def test_tensor_parallel_engine_two_ranks_one_gpu(tiny_dir, tmp_path):
         assert rel < tol, (name, float(rel))
         assert all(len(t) == 6 for t in tp2[name]["tokens"])
         assert tp2[name]["head_equal"], "vocabulary-parallel fused sampler differs from the unsharded one"
+    # the one-shot all-reduce: used (calls were made, no wait timed out), and with two ranks the f32 sum of two bf16
+    # partials rounds exactly like the process group's bf16 sum, so tokens and hidden states equal the library path's
+    one = tp2["w8a16_oneshot"]
+    assert one["comm"] and all(calls > 0 and timeouts == 0 for calls, timeouts in one["comm"].values()), one["comm"]
+    assert one["tokens"] == tp2["w8a16"]["tokens"]
+    assert torch.equal(one["hidden"], tp2["w8a16"]["hidden"])
 
 
 @pytest.mark.parametrize("quant", [dict(quant_type="per_row_weight_only", linear_dtype=torch.int8),

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1
-time timeout -k 10 900 python -u bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err
+timeout -k 10 400 python -u -m pytest tests/test_gpu_engine.py -x -q --timeout 200 --timeout-method thread -k "two_ranks" > gpurun_out/r3_ar.log 2>&1
 rc=$?
-
-tail -5 gpurun_out/r3_bench.err | cut -c1-300
+tail -40 gpurun_out/r3_ar.log | cut -c1-250
 exit $rc
