@@ -308,6 +308,18 @@ class ModelRunner:
         # (no_grad, not inference_mode: the first capture of a process creates the RNG bookkeeping tensors that
         # every later capture updates in place, and as inference tensors they would make a capture that anybody
         # starts outside inference mode fail for as long as these graphs live)
+        # (the buffers the graphs address are created here: on this runner's device and in the model's dtype, whoever
+        # calls - the constructor, or a caller that re-captures after changing the model)
+        prev_dtype, prev_device = torch.get_default_dtype(), torch.get_default_device()
+        torch.set_default_dtype(self.config.hf_config.torch_dtype)
+        torch.set_default_device(self.device)
+        try:
+            self._capture_graphs()
+        finally:
+            torch.set_default_device(prev_device)
+            torch.set_default_dtype(prev_dtype)
+
+    def _capture_graphs(self):
         cfg, hf = self.config, self.config.hf_config
         max_bs = min(cfg.max_num_seqs, 512)
         self.max_graph_bs = max_bs

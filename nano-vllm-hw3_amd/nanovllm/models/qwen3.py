@@ -115,6 +115,7 @@ class ParallelLMHead(VocabParallelEmbedding):
     def __init__(self, num_embeddings: int, embedding_dim: int):
         super().__init__(num_embeddings, embedding_dim)
         self.quantized = None     # a per-row W8A16 QLinear over this rank's vocabulary shard (opt-in: quantize_lm_head)
+        self.force_exchange = False    # tests: run the shard-maxima exchange (all_gather_into_tensor) on a one-rank group
 
     def fused_sampler(self, x):
         """True when greedy_tokens(x) can run: bf16 table (or this rank's shard of it) on this GPU, K a multiple of 32."""
@@ -127,7 +128,7 @@ class ParallelLMHead(VocabParallelEmbedding):
         parallel ranks take the maximum over their shard and exchange {winning logit, token} pairs (8 bytes per row
         and rank) where the reference gathers the shards' logits (embed_head.py:62-65)."""
         from nanovllm import ops
-        if self.tp_size == 1:
+        if self.tp_size == 1 and not self.force_exchange:
             return ops.lm_head_argmax(x, self.weight, out=out)
         tok, val = ops.lm_head_argmax(x, self.weight, return_max=True)
         tok = tok + self.start

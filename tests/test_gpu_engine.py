@@ -711,6 +711,61 @@ def test_row_parallel_slab_pipeline_on_rccl():
         dist.destroy_process_group()
 
 
+def test_tensor_parallel_decode_step_captured_on_rccl(tiny_dir):
+    """What a multi-GPU run of the benchmark does in every decode step, on the collective library itself: a model whose
+    modules play their tensor-parallel roles (vocabulary-parallel embedding with its all-reduce, row-parallel o_proj /
+    down_proj with the side-stream all-reduce, the sampler's exchange of shard maxima through all_gather_into_tensor)
+    is captured into the decode hipGraphs in "thread_local" capture mode on an RCCL group.  One GPU, so the group has
+    one rank and every collective is the identity: captured tokens == eager tokens == tokens of the role-free model."""
+    import torch.distributed as dist
+    from nanovllm import LLM, SamplingParams
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29716")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        kw = dict(load_format="dummy", max_model_len=512, max_num_seqs=16, quant_type="per_row_weight_only",
+                  linear_dtype=torch.int8)
+        sp = SamplingParams(max_tokens=12, ignore_eos=True)
+        llm = LLM(tiny_dir, enforce_eager=True, **kw)
+        before = [o["token_ids"] for o in llm.generate(_prompts(), sp)]
+        runner = llm.model_runner
+        model = runner.model
+        model.model.embed_tokens.tp_size = 2                      # (the whole table is this rank's "shard")
+        for layer in model.model.layers:
+            layer.self_attn.o_proj._init_tp(1, 0, 2)              # row-parallel shard of a 2-way group
+            layer.mlp.down_proj._init_tp(1, 0, 2)
+        model.lm_head.force_exchange = True
+        calls = {"all_reduce": 0, "all_gather": 0}
+        real_ar, real_ag = dist.all_reduce, dist.all_gather_into_tensor
+
+        def counting_ar(*a, **k):
+            calls["all_reduce"] += 1
+            return real_ar(*a, **k)
+
+        def counting_ag(*a, **k):
+            calls["all_gather"] += 1
+            return real_ag(*a, **k)
+        dist.all_reduce, dist.all_gather_into_tensor = counting_ar, counting_ag
+        try:
+            assert [o["token_ids"] for o in llm.generate(_prompts(), sp)] == before          # eager, with the collectives
+            n_layers = len(model.model.layers)
+            assert calls["all_reduce"] >= 2 * n_layers + 1 and calls["all_gather"] >= 2
+            runner.world_size = 2                                     # -> capture_error_mode="thread_local"
+            calls.update(all_reduce=0, all_gather=0)
+            runner.capture_graphs()
+            # every captured step issued its collectives under capture: embedding + 2 per layer, and the sampler's two
+            assert calls["all_reduce"] >= len(runner.graph_bs) * (2 * n_layers + 1)
+            assert calls["all_gather"] >= 2 * len(runner.graph_bs)
+        finally:
+            dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
+        runner.enforce_eager = False
+        assert [o["token_ids"] for o in llm.generate(_prompts(), sp)] == before              # replayed graphs
+        assert [o["token_ids"] for o in llm.generate(_prompts(), sp)] == before
+    finally:
+        dist.destroy_process_group()
+
+
 def _tp_worker(rank, world, port, model_dir, out_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
