@@ -51,6 +51,15 @@ const char* ql_last_error(void);
 int ql_quant_per_row(int dtype, const void* x_bf16, int64_t T, int64_t H, void* q, float* scale,
                      void* stream);
 
+/* per_row_quant on activations that are not bf16: the reference's kernel converts whatever it loads to f32
+ * (`.to(tl.float32)`, quantization.py:27), so fp16 and fp32 inputs go through the same arithmetic on the widened
+ * values.  in_dtype: QL_IN_BF16 (= ql_quant_per_row), QL_IN_F16, QL_IN_F32. */
+#define QL_IN_BF16 0
+#define QL_IN_F16 1
+#define QL_IN_F32 2
+int ql_quant_per_row_wide(int dtype, int in_dtype, const void* x, int64_t T, int64_t H, void* q, float* scale,
+                          void* stream);
+
 /* per_tensor_quant (:166-191).  One scale for the whole [N,K] bf16 tensor; amax, scale and x/scale
  * are rounded to bf16 as the reference's bf16 tensor arithmetic does; int8 uses round-half-even +
  * clamp(-128,127).  `scale` receives the (bf16-valued) scale as f32.  `workspace` >= 16 bytes. */

@@ -66,6 +66,52 @@ __global__ __launch_bounds__(256) void quant_per_row_kernel(const unsigned short
     }
 }
 
+// the same for activations that arrive as fp16 or fp32 (IN = 1 / 2): the reference's kernel converts whatever it loads
+// to f32 first (quantization.py:27), so the arithmetic is that of the bf16 form on the widened values
+template <int DT, int IN>
+__global__ __launch_bounds__(256) void quant_per_row_wide_kernel(const void* __restrict__ xv, unsigned char* __restrict__ q,
+                                                                 float* __restrict__ scale, int64_t H) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    auto load8 = [&](int64_t c, float* f) {
+        if constexpr (IN == 1) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            const f16x8 v = *(const f16x8*)((const _Float16*)xv + row * H + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+        } else {
+            const float4 a = *(const float4*)((const float*)xv + row * H + c), b = *(const float4*)((const float*)xv + row * H + c + 4);
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+        }
+    };
+    float m = 0.f;
+    for (int64_t c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        float f[8];
+        load8(c, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
+    }
+    m = block_max_256(m, sh);
+    const float row_max = fmaxf(m, 1e-8f);
+    const float sc_inv = QMax<DT>::v / row_max;
+    if (threadIdx.x == 0) scale[row] = row_max / QMax<DT>::v;
+    unsigned char* qr = q + row * H;
+    for (int64_t c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        float f[8];
+        load8(c, f);
+        unsigned long long out = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = f[j] * sc_inv;
+            unsigned b;
+            if (DT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)roundf(y);
+            else b = f32_to_e4m3fn(y);
+            out |= (unsigned long long)b << (8 * j);
+        }
+        *(unsigned long long*)(qr + c) = out;
+    }
+}
+
 // ---- partial row maxima: out[row][i] = max |x[row, i*H/parts : (i+1)*H/parts]| (one wave per part) ----
 __global__ __launch_bounds__(256) void row_absmax_parts_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
                                                                int64_t H, int parts) {
@@ -270,6 +316,27 @@ extern "C" {
 
 int ql_version(void) { return 1; }
 const char* ql_last_error(void) { return ql::g_err; }
+
+int ql_quant_per_row_wide(int dtype, int in_dtype, const void* x, int64_t T, int64_t H, void* q, float* scale, void* stream) {
+    const char* fn = "ql_quant_per_row_wide";
+    if (in_dtype == QL_IN_BF16) return ql_quant_per_row(dtype, x, T, H, q, scale, stream);
+    if ((dtype != QL_INT8 && dtype != QL_FP8) || (in_dtype != QL_IN_F16 && in_dtype != QL_IN_F32) || T < 0 || H <= 0 ||
+        (T > 0 && (!x || !q || !scale))) {
+        set_error("%s: bad argument (dtype=%d in_dtype=%d T=%lld H=%lld)", fn, dtype, in_dtype, (long long)T, (long long)H);
+        return QL_EINVAL;
+    }
+    if (H % 8) { set_error("%s: H=%lld must be a multiple of 8", fn, (long long)H); return QL_ESHAPE; }
+    if (T == 0) return QL_OK;
+    if (T > 0x7FFFFFFF) { set_error("%s: T too large", fn); return QL_ESHAPE; }
+    dim3 grid((unsigned)T), block(256);
+    hipStream_t s = as_stream(stream);
+#define QL_QW(DT_, IN_) hipLaunchKernelGGL((quant_per_row_wide_kernel<DT_, IN_>), grid, block, 0, s, x, (unsigned char*)q, scale, H)
+    if (dtype == QL_INT8) { if (in_dtype == QL_IN_F16) QL_QW(QL_INT8, 1); else QL_QW(QL_INT8, 2); }
+    else { if (in_dtype == QL_IN_F16) QL_QW(QL_FP8, 1); else QL_QW(QL_FP8, 2); }
+#undef QL_QW
+    QL_CHECK_LAUNCH(fn);
+    return QL_OK;
+}
 
 int ql_quant_per_row(int dtype, const void* x, int64_t T, int64_t H, void* q, float* scale, void* stream) {
     if ((dtype != QL_INT8 && dtype != QL_FP8) || (T > 0 && (!x || !q || !scale)) || T < 0 || H <= 0) {

@@ -24,6 +24,7 @@ SIGNATURES = {
     "ql_version": (_c_int, []),
     "ql_last_error": (ctypes.c_char_p, []),
     "ql_quant_per_row": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp]),
+    "ql_quant_per_row_wide": (_c_int, [_c_int, _c_int, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp]),
     "ql_quant_per_tensor": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp]),
     "ql_quant_per_group": (_c_int, [_c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),
     "ql_fake_quant": (_c_int, [_c_int, _c_int, _c_vp, _c_i64, _c_i64, _c_int, _c_vp, _c_vp, _c_vp]),

@@ -44,16 +44,27 @@ def _ws16(device):
     return _scratch16[key]
 
 
+# activations that are not bf16: fp16 / fp32, as the reference's matmuls accept them (they compute in fp32 and return
+# x's dtype: quantization.py:258-259, 302, 329); value = the library's QL_IN_* code
+_WIDE = {torch.float16: 1, torch.float32: 2}
+
+
 # --------------------------------------------------------------------------- quantizers
 @torch.no_grad()
 def per_row_quant(x: torch.Tensor, dtype: torch.dtype):
-    """x [T, H] bf16 -> (q [T, H] dtype, scale [T] f32).  Reference: quantization.py:147-163."""
+    """x [T, H] bf16 (or fp16 / fp32: the reference's kernel widens whatever it loads to f32, quantization.py:27)
+    -> (q [T, H] dtype, scale [T] f32).  Reference: quantization.py:147-163."""
     assert dtype in _DTYPES
     assert x.dim() == 2
-    Q.require_cuda(x, torch.bfloat16, "x")
     T, H = x.shape
     qx = torch.empty_like(x, dtype=dtype)
     sx = torch.empty((T,), dtype=torch.float32, device=x.device)
+    if x.dtype in _WIDE:
+        Q.require_cuda(x, x.dtype, "x")
+        Q.check(Q.load().ql_quant_per_row_wide(Q.dtype_code(dtype), _WIDE[x.dtype], x.data_ptr(), T, H, qx.data_ptr(),
+                                               sx.data_ptr(), Q.stream_ptr(x.device)))
+        return qx, sx
+    Q.require_cuda(x, torch.bfloat16, "x")
     Q.check(Q.load().ql_quant_per_row(Q.dtype_code(dtype), x.data_ptr(), T, H, qx.data_ptr(), sx.data_ptr(),
                                       Q.stream_ptr(x.device)))
     return qx, sx
@@ -138,8 +149,60 @@ def _wcode(qw, dtype):
     return Q.dtype_code(dtype) | (Q.QL_TILED if isinstance(qw, TiledWeight) else 0)
 
 
+def _bf16_terms(x2):
+    """fp16 / fp32 activations as a sum of bf16 tensors, exactly: an fp16 value is the sum of two bf16 values (its
+    leading 8 significant bits, and the rest), an fp32 value of three."""
+    xf = x2.float()
+    terms = []
+    for _ in range(2 if x2.dtype == torch.float16 else 3):
+        t = xf.to(torch.bfloat16)
+        terms.append(t.contiguous())
+        xf = xf - t.float()
+    return terms
+
+
+def _w8a16_wide(x, qw, sw32, bias, granularity, group_size, dtype, silu):
+    """The weight-only matmuls on fp16 / fp32 activations (reference: ``x.float() @ w.T`` in fp32, result cast to x's
+    dtype, quantization.py:258-261, 299-305).  The activations are split exactly into bf16 terms; every term runs the
+    same MFMA kernels in their deferred form (unscaled f32 partial sums, ql_gemm_w8a16_partial), and the f32 slices of
+    all terms are added up, scaled and cast once - so the result carries x's precision, not bf16's."""
+    lib = Q.load()
+    N, K = qw.shape
+    x2 = x.reshape(-1, K).contiguous()
+    M = x2.shape[0]
+    acc = torch.zeros((M, N), dtype=torch.float32, device=x.device)
+    if M > 0:
+        S = lib.ql_gemm_partial_slices(M, N, K, granularity)
+        parts = torch.empty((max(S, 1), M, N), dtype=torch.float32, device=x.device)
+        for t in _bf16_terms(x2):
+            Q.check(lib.ql_gemm_w8a16_partial(_wcode(qw, dtype), granularity, t.data_ptr(), qw.data_ptr(), sw32.data_ptr(), M, N,
+                                              K, group_size or 0, parts.data_ptr(), S, Q.stream_ptr(x.device)))
+            for s_ in range(max(S, 1)):
+                acc += parts[s_]
+    if granularity == Q.QL_PER_ROW:
+        y = acc * sw32[None, :]
+        y = (y + bias.float()[None, :]) if bias is not None else y              # bf16((sum * s) + b): one rounding
+        y = y.to(x.dtype)
+    else:
+        if granularity == Q.QL_PER_TENSOR:
+            acc = acc * sw32.reshape(1, 1)
+        y = acc.to(x.dtype)
+        if bias is not None:
+            y = y + bias.to(x.dtype)[None, :]                                       # (the reference adds it after the cast)
+    if silu:                                                                        # rows interleaved in 32-row gate / up strips
+        g = y.view(M, N // 64, 2, 32)
+        y = (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
+    return y.view(*x.shape[:-1], y.shape[-1])
+
+
 def _w8a16(x, qw, sw, bias, granularity, group_size, dtype, silu=False, out=None):
     assert dtype in _DTYPES and qw.dtype == dtype
+    if x.dtype in _WIDE:
+        assert out is None and x.shape[-1] == qw.shape[1]
+        Q.require_cuda(x.reshape(-1, x.shape[-1]), x.dtype, "x")
+        sw_ = sw if sw.dtype == torch.float32 else sw.to(torch.float32)
+        sw_ = Q.require_cuda(sw_.reshape(-1) if sw_.dim() == 0 else sw_, torch.float32, "sw")
+        return _w8a16_wide(x, qw, sw_, bias, granularity, group_size, dtype, silu)
     x2, y_shape = _flatten(x, qw.shape[0] // 2 if silu else qw.shape[0])
     Q.require_cuda(x2, torch.bfloat16, "x")
     Q.require_cuda(qw, dtype, "qw")
@@ -275,9 +338,39 @@ def w8a8_dynq_matmul(x, rowmax_part, qw, sw, bias, dtype, out=None):
     return y if out is not None else y.view(y_shape)
 
 
+def _per_row_matmul_wide(x, qw, sw, bias, dtype, silu):
+    """per_row_matmul on fp16 / fp32 activations: the quantizer widens them to f32 (as the reference's does), the
+    contraction runs in the deferred form (raw int32 / f32 slices) and the reference's epilogue
+    ``(acc * sx[m]) * sw[n] (+ bias)`` -> x's dtype (quantization.py:111-144) is applied to the summed slices."""
+    lib = Q.load()
+    N, K = qw.shape
+    x2 = x.reshape(-1, K).contiguous()
+    M = x2.shape[0]
+    qx, sx = per_row_quant(x2, dtype)
+    is_int = dtype == torch.int8
+    S = lib.ql_gemm_partial_slices(M, N, K, Q.QL_PER_ROW) if M > 0 else 1
+    parts = torch.zeros((max(S, 1), M, N), dtype=torch.int32 if is_int else torch.float32, device=x.device)
+    if M > 0:
+        Q.check(lib.ql_gemm_w8a8_partial(_wcode(qw, dtype), qx.data_ptr(), qw.data_ptr(), M, N, K, parts.data_ptr(), S,
+                                         Q.stream_ptr(x.device)))
+    acc = parts[0].clone()
+    for s_ in range(1, max(S, 1)):
+        acc += parts[s_]
+    y = acc.float() * sx[:, None] * sw[None, :]
+    if bias is not None:
+        y = y + bias.float()[None, :]
+    y = y.to(x.dtype)
+    if silu:
+        g = y.view(M, N // 64, 2, 32)
+        y = (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
+    return y.view(*x.shape[:-1], y.shape[-1])
+
+
 @torch.no_grad()
 def per_row_matmul(x, qw, sw, bias, dtype, silu=False, out=None):
     """Dynamic per-token activation quant + W8A8 GEMM (quantization.py:310-346)."""
+    if x.dtype in _WIDE:
+        return _per_row_matmul_wide(x, qw, sw, bias, dtype, silu)
     x2, y_shape = _flatten(x, qw.size(0) // 2 if silu else qw.size(0))
     assert x2.size(1) % 32 == 0, f"K({x2.size(1)}) must be multiple of 32"
     qx, sx = per_row_quant(x2.contiguous(), dtype)

@@ -120,7 +120,10 @@ def per_row_quant(x_bf16, dtype, return_scaled=False):
       y = x * scale_inv; int8: roundf(y) -> int8 ; fp8: cast(y) to e4m3fn.
     Returns (q [T,H] int8|uint8, scale [T] f32); with ``return_scaled`` the f32 values y in front of
     the narrowing cast instead of q."""
-    x = bf16_to_f32(x_bf16)
+    # (bf16 bit patterns, or - as the kernel takes any float type and widens it to f32, quantization.py:27 - a float
+    # array: fp16 / fp32 activations)
+    x = np.asarray(x_bf16)
+    x = x.astype(np.float32) if x.dtype.kind == "f" else bf16_to_f32(x)
     assert x.ndim == 2
     Q = np.float32(QMAX[dtype])
     row_max = np.maximum(np.abs(x).max(axis=1), np.float32(1e-8)).astype(np.float32)

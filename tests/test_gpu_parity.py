@@ -762,6 +762,77 @@ def test_group_sizes_unrelated_to_the_chunk_length(NQ, g, tile):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+# ----------------------------------------------------------------------------- fp16 / fp32 activations
+@pytest.mark.parametrize("xdt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mnk", [(1, 64, 128), (5, 96, 256), (70, 200, 1184), (300, 256, 3072)])
+def test_fp16_fp32_activations(NQ, xdt, dt, mnk):
+    """The reference's matmuls take activations of any float type, compute in fp32 and return x's dtype
+    (quantization.py:258-261, 299-305, 319-346).  Weight-only: the activations are split exactly into bf16 terms and
+    the f32 slices of every term are summed, so the result must carry x's precision (half an ulp of x's dtype + the
+    f32 accumulation allowance), not bf16's.  W8A8 int8: quantizer, integer contraction and the f32 epilogue are exact,
+    so the result is bit-identical to the oracle's arithmetic cast to x's dtype."""
+    M, N, K = mnk
+    rng = np.random.default_rng(M + N + K)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(xdt).cuda()
+    xf = x.float().cpu().numpy()
+    wb = rand_bf16(rng, (N, K), 0.05)
+    bias = bf16_t(rand_bf16(rng, (N,), 0.5))
+    ulp = 2.0 ** -11 if xdt == torch.float16 else 2.0 ** -24
+
+    def close(y, ref64, l1, what, first=None):
+        """``first``: the value that was rounded to x's dtype before the bias was added in x's dtype (the reference's
+        order for per-group / per-tensor): two roundings, the first one at the magnitude of that value."""
+        assert y.dtype == xdt and tuple(y.shape) == ref64.shape
+        got = y.float().cpu().numpy().astype(np.float64)
+        tol = 1.002 * ulp * (np.abs(ref64) + (0 if first is None else np.abs(first))) + 2.0 ** -17 * l1 + 1e-30
+        bad = np.abs(got - ref64) > tol
+        assert not bad.any(), (what, int(bad.sum()), float(np.abs(got - ref64).max()))
+
+    # per-row weight-only, per-group, per-tensor
+    qo, so = O.per_row_quant(wb, dt)
+    deq = O._decode_q(qo, dt).astype(np.float64) * so[:, None]
+    l1 = np.abs(xf).astype(np.float64) @ np.abs(deq).T
+    for b in (None, bias):
+        bb = 0 if b is None else O.bf16_to_f32(bits16(b)).astype(np.float64)[None, :]
+        y = NQ.per_row_weight_only_matmul(x, q_t(qo, dt), torch.from_numpy(so).cuda(), b, TDT[dt])
+        close(y, xf.astype(np.float64) @ deq.T + bb, l1, f"per-row weight-only {xdt} {dt}")
+    g = 32 if K % 128 else 128
+    qg, sg = O.per_group_quant(wb, g, dt)
+    deq = (O._decode_q(qg, dt).reshape(N, -1, g) * sg[..., None]).reshape(N, K).astype(np.float64)
+    y = NQ.per_group_matmul(x, q_t(qg, dt), torch.from_numpy(sg).cuda(), bias, g, TDT[dt])
+    close(y, xf.astype(np.float64) @ deq.T + O.bf16_to_f32(bits16(bias)).astype(np.float64)[None, :],
+          np.abs(xf).astype(np.float64) @ np.abs(deq).T, f"per-group {xdt} {dt}", first=xf.astype(np.float64) @ deq.T)
+    qt, st = O.per_tensor_quant(wb, dt)
+    st = float(np.asarray(st).reshape(-1)[0])
+    deq = O._decode_q(qt, dt).astype(np.float64) * st
+    y = NQ.per_tensor_matmul(x, q_t(qt, dt), torch.tensor(st, dtype=torch.bfloat16).cuda(), None, TDT[dt])
+    close(y, xf.astype(np.float64) @ deq.T, np.abs(xf).astype(np.float64) @ np.abs(deq).T, f"per-tensor {xdt} {dt}")
+    # the quantizer on the widened values: bit-exact; the W8A8 matmul: int8 bit-exact, fp8 at the fp8 GEMM's tolerance
+    qx, sx = NQ.per_row_quant(x, TDT[dt])
+    qxo, sxo = O.per_row_quant(xf, dt)
+    assert np.array_equal(bits8(qx), np.asarray(qxo).view(np.uint8)) and np.array_equal(sx.cpu().numpy(), sxo)
+    y8 = NQ.per_row_matmul(x, q_t(qo, dt), torch.from_numpy(so).cuda(), None, TDT[dt])
+    assert y8.dtype == xdt
+    accd = O._decode_q(qxo, dt).astype(np.float64) @ O._decode_q(qo, dt).astype(np.float64).T
+    if dt == "int8":
+        want = ((accd.astype(np.float32) * sxo[:, None]).astype(np.float32) * so[None, :]).astype(np.float32)
+        want = torch.from_numpy(want).to(xdt)
+        assert torch.equal(y8.cpu(), want)
+    else:
+        ref = accd * sxo[:, None].astype(np.float64) * so[None, :].astype(np.float64)
+        l18 = (np.abs(O._decode_q(qxo, dt)).astype(np.float64) @ np.abs(O._decode_q(qo, dt)).astype(np.float64).T) \
+            * sxo[:, None] * so[None, :]
+        close(y8, ref, l18, f"w8a8 fp8 {xdt}")
+    # the fused SiLU form (interleaved weight) == the plain form followed by SiluAndMul in x's dtype
+    if N % 64 == 0:
+        il = NQ.interleave_gate_up
+        qw_t, sw_t = q_t(qo, dt), torch.from_numpy(so).cuda()
+        plain = NQ.per_row_weight_only_matmul(x, qw_t, sw_t, None, TDT[dt])
+        fused = NQ.per_row_weight_only_matmul(x, il(qw_t), il(sw_t), None, TDT[dt], silu=True)
+        assert torch.equal(fused, torch.nn.functional.silu(plain[:, :N // 2]) * plain[:, N // 2:])
+
+
 # ----------------------------------------------------------------------------- edge cases / API behaviour
 def test_empty_and_leading_dims(NQ):
     w = torch.randn(64, 128, device="cuda", dtype=torch.bfloat16)
@@ -783,7 +854,7 @@ def test_errors_are_loud(NQ):
     with pytest.raises(AssertionError):
         NQ.per_row_quant(w, torch.float16)
     with pytest.raises(Q.QLinearError):
-        NQ.per_row_quant(w.float(), torch.int8)        # only bf16 inputs are implemented
+        NQ.per_row_quant(w.double(), torch.int8)       # bf16, fp16 and fp32 inputs are implemented
     w104 = torch.randn(64, 104, device="cuda", dtype=torch.bfloat16)
     qw, sw = NQ.per_row_quant(w104, torch.int8)
     with pytest.raises(Q.QLinearError):                # K = 104 is not a multiple of 32
