@@ -58,7 +58,7 @@ def gemm_bytes(M, N, K, n_out=None):
     return N * K + 4 * N + 2 * M * K + 2 * M * (N if n_out is None else n_out)
 
 
-TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r02_decode_gemm_traffic.json")
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r03_decode_gemm_traffic.json")
 
 
 def pmc_traffic(mods4, buckets):

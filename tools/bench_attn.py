@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vllm-hw3_amd"))
 from nanovllm import ops
 torch.manual_seed(0)
-B, Hq, Hkv, D, bs = 131, int(os.environ.get("HQ", "16")), 8, 128, 256      # HQ=32: the Qwen3-4B / 8B head ratio
+B, Hq, Hkv, D, bs = int(os.environ.get("BATCH", "131")), int(os.environ.get("HQ", "16")), 8, 128, 256      # HQ=32: the Qwen3-4B / 8B head ratio
 lens = torch.randint(300, 1800, (B,))
 nblk = int(((lens + bs - 1) // bs).sum()) + 1
 L = 8   # layers' worth of distinct caches so that the KV streams from HBM

@@ -1,6 +1,14 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1
-timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -x -q --timeout 200 --timeout-method thread -k "fp16_fp32 or errors_are_loud or empty_and" > gpurun_out/r3_wide.log 2>&1
-rc=$?
-grep -v "^  File" gpurun_out/r3_wide.log | tail -30 | cut -c1-300
-exit $rc
+for B in 32 64 131 256; do
+ for S in 1 2 4 8; do
+  echo "B=$B SPW=$S"; BATCH=$B QL_ATTN_SPW=$S timeout -k 10 120 python -u tools/bench_attn.py || exit 1
+ done
+done > gpurun_out/r3_attn_spw.log 2>&1
+echo HQ32 >> gpurun_out/r3_attn_spw.log
+for B in 131 256; do
+ for S in 1 8; do
+  echo "B=$B SPW=$S HQ=32"; HQ=32 BATCH=$B QL_ATTN_SPW=$S timeout -k 10 120 python -u tools/bench_attn.py || exit 1
+ done
+done >> gpurun_out/r3_attn_spw.log 2>&1
+cat gpurun_out/r3_attn_spw.log

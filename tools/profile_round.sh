@@ -3,7 +3,7 @@
 # over the prefill GEMM.  Every step has its own time limit; the script stops at the first failure.
 set -e
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -11,6 +11,9 @@ timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ben
 find $O/bench -name "*kernel_trace.csv" -delete          # (hundreds of thousands of rows; the stats file is what is kept)
 grep -c . $(find $O/bench -name "*kernel_stats.csv") | head -1
 echo "kernel-trace done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench4b -- python3 $R/bench.py --model 4b --quant per_group --no-cpu-baseline --no-extra-configs > $O/bench4b.log 2>&1
+find $O/bench4b -name "*kernel_trace.csv" -delete
+echo "4B g128 kernel-trace done"
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 -u $R/tools/pmc_traffic.py > $O/fetch.log 2>&1
 echo "fetch pass done"
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 -u $R/tools/pmc_traffic.py > $O/write.log 2>&1
