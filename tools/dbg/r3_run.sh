@@ -1,14 +1,16 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1
-for B in 32 64 131 256; do
- for S in 1 2 4 8; do
-  echo "B=$B SPW=$S"; BATCH=$B QL_ATTN_SPW=$S timeout -k 10 120 python -u tools/bench_attn.py || exit 1
- done
-done > gpurun_out/r3_attn_spw.log 2>&1
-echo HQ32 >> gpurun_out/r3_attn_spw.log
-for B in 131 256; do
- for S in 1 8; do
-  echo "B=$B SPW=$S HQ=32"; HQ=32 BATCH=$B QL_ATTN_SPW=$S timeout -k 10 120 python -u tools/bench_attn.py || exit 1
- done
-done >> gpurun_out/r3_attn_spw.log 2>&1
-cat gpurun_out/r3_attn_spw.log
+MS=16,32,64,96,128,192,256,384,512
+for mode in bf16 w8a16 group w8a8; do
+  echo "== $mode"
+  timeout -k 10 200 python -u tools/bench_kernels.py --model 4b --mode $mode --ms $MS --iters 40 --tiled || exit 1
+done > gpurun_out/r3_midm_calib.log 2>&1
+grep -v amdgpu.ids gpurun_out/r3_midm_calib.log | python3 -c "
+import sys, json
+mode=None; t={}
+for l in sys.stdin:
+    if l.startswith('=='): mode=l.split()[1]; continue
+    if not l.startswith('{'): continue
+    r=json.loads(l); t.setdefault((r['shape'],r['M']),{})[mode]=r['us']
+for k,v in t.items(): print(k, v)
+"
