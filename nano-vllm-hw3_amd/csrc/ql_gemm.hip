@@ -55,6 +55,13 @@ static bool sk_tile_built(int mt, int wn, int wk, int cp, bool group, bool rope)
 
 // GemmParams::gmagic for a group size (a multiple of 32): with d = group / 32 and m = ceil(2^32 / d),
 // umulhi(q, m) == q / d for all q < 2^32 / d, far beyond any K / 32 that passes check_common
+// A/B switch for the per-group kernels: QL_GROUP_GENERIC=1 keeps them off the group-aligned form of their main loop
+// (identical results; read once, not per launch)
+static int group_generic() {
+    static const int v = getenv("QL_GROUP_GENERIC") != nullptr ? 1 : 0;
+    return v;
+}
+
 static unsigned group_magic(int group) {
     const unsigned d = (unsigned)group / 32u;
     return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d);
@@ -502,7 +509,7 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     GemmParams p{};
     p.x = (const unsigned char*)x; p.w = (const unsigned char*)qw; p.sw = sw; p.sx = nullptr;
     p.bias = (const unsigned short*)bias; p.y = (unsigned short*)y; p.partial = nullptr; p.counters = nullptr;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = grp ? group : 0; p.gmagic = grp ? group_magic(group) : 0;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = grp ? group : 0; p.gmagic = grp ? group_magic(group) : 0; p.group_generic = group_generic();
     p.sw_stride = granularity == QL_PER_ROW ? 1 : 0;
     p.bias_after_round = granularity == QL_PER_ROW ? 0 : 1;
     p.silu = silu ? 1 : 0;
@@ -616,7 +623,7 @@ int ql_gemm_w8a16_partial(int wdtype, int granularity, const void* x, const void
     }
     GemmParams p{};
     p.x = (const unsigned char*)x; p.w = (const unsigned char*)qw; p.sw = sw;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = grp ? group : 0; p.gmagic = grp ? group_magic(group) : 0;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group = grp ? group : 0; p.gmagic = grp ? group_magic(group) : 0; p.group_generic = group_generic();
     p.sw_stride = granularity == QL_PER_ROW ? 1 : 0;
     p.wtiled = tiled ? 1 : 0;
     p.partial_rm = partials;

@@ -54,6 +54,7 @@ struct GemmParams {
                                  // sums row-major and the NEXT launch (ql_add_rmsnorm_partial) adds the slices up
     int M, N, K;
     int group;                   // group size (per-group only)
+    int group_generic;           // 1: never take the group-aligned form of the main loop (A/B checks; same bits either way)
     unsigned gmagic;             // ceil(2^32 / (group / 32)): k / group = umulhi(k >> 5, gmagic) for every k < 2^31 the
                                  // kernels see (0 when group / 32 is 1: the quotient is k >> 5 itself)
     int sw_stride;               // 1 per-row, 0 per-tensor
@@ -502,7 +503,7 @@ void qgemm_kernel(const GemmParams p) {
     // operands they keep in flight - at every group end.
     float s_ahead = 0.f;
     if constexpr (GROUP && !SLDS) s_ahead = p.sw[(size_t)nrow * ngk + min(gdiv(min(k0 + wk * C::KW, p.K - 32)), ngk - 1)];
-    auto flush_group = [&](int kb, int kc, int buf, int c) {
+    auto flush_group = [&](int kb, int kc, int buf, int c, bool clear) __attribute__((always_inline)) {
         // fold the finished group's partial sums into the running sum with the group's f32 scale
         float s;
         if constexpr (SLDS) {
@@ -525,13 +526,24 @@ void qgemm_kernel(const GemmParams p) {
                 const f32x2 o2 = __builtin_elementwise_fma(g2, s2, a2);
                 acc[i][r] = o2[0];
                 acc[i][r + 1] = o2[1];
-                accg[i][r] = 0;
-                accg[i][r + 1] = 0;
+                if (clear) {
+                    accg[i][r] = 0;
+                    accg[i][r + 1] = 0;
+                }
             }
     };
     // one 32-k step of this wave: widen the 16 weight bytes of the lane, MT x (A fragment reads + MFMAs)
     wreg_t w_even{};                                              // (fp8 x fp8: the even step's weights, see below)
-    auto step = [&](auto chk, int buf, int kc, int c, const wreg_t w) {
+    // GM (per-group kernels): where the groups lie relative to the steps, when the host-side shape makes that a
+    // compile-time fact.  0: anything (tested per step).  1: group = 128 k and the wave's chunk part is a whole number
+    // of groups (CP % 4 == 0): step ph starts a group when ph % 4 == 0 and ends one when ph % 4 == 3.  2 / 3: group =
+    // 128 k, chunk part = 64 k (CP == 2, WK == 1), this chunk is the first / second half of a group.  In the modes
+    // 1-3 the first MFMA of a group takes a ZERO C operand instead of the group accumulator, which then never needs
+    // clearing (two thirds of the fold's instructions); the sums are the same bit for bit (0 + a b).
+    // ph = the step's position in the chunk as the unrolled loops know it at compile time (ph % 4 == c % 4).
+    auto step = [&](auto chk, auto gmc, int buf, int kc, int c, int ph, const wreg_t w) __attribute__((always_inline)) {
+        constexpr int GM = decltype(gmc)::value;
+        const bool gstart = (GM == 1 && (ph & 3) == 0) || (GM == 2 && ph == 0);
         const int kb = kc + wk * C::KW + c * 32;   // first k of this step (wave-uniform)
         if (decltype(chk)::value && kb >= kend) return;
         const int base_c = (wk * CP + c) * APS;    // first piece of the step in an LDS row (uniform)
@@ -553,7 +565,8 @@ void qgemm_kernel(const GemmParams p) {
                 const bf16x8 alo = *(const bf16x8*)(smem + a0 + i * 32 * RB);
                 const bf16x8 ahi = *(const bf16x8*)(smem + a1 + i * 32 * RB);
                 if (GROUP) {
-                    accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, accg[i], 0, 0, 0);
+                    if (gstart) accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, f32x16{}, 0, 0, 0);
+                    else accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, accg[i], 0, 0, 0);
                     accg[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, accg[i], 0, 0, 0);
                 } else {
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, blo, acc[i], 0, 0, 0);
@@ -607,7 +620,12 @@ void qgemm_kernel(const GemmParams p) {
             // starts at another k: it may belong to another group or continue this one, and both are handled
             // by scaling what has been summed so far with the current group's scale).  Any group size that is
             // a multiple of the 32-k step is exact this way, whatever its relation to the chunk length.
-            if (gdiv(kb + 32) * p.group == kb + 32 || c == CP - 1 || kb + 32 >= kend) flush_group(kb, kc, buf, c);
+            if constexpr (GM == 0) {
+                if (gdiv(kb + 32) * p.group == kb + 32 || c == CP - 1 || kb + 32 >= kend) flush_group(kb, kc, buf, c, true);
+            } else {
+                // (slices start and end on group boundaries in these modes: a group is never cut)
+                if ((GM == 1 && (ph & 3) == 3) || (GM == 3 && ph == CP - 1)) flush_group(kb, kc, buf, c, false);
+            }
         }
     };
 
@@ -622,7 +640,7 @@ void qgemm_kernel(const GemmParams p) {
         const int kb = min(kc + wk * C::KW + c * 32, kend - 32);
         return load_w_at(kb);
     };
-    auto chunk_db = [&](auto chk, int it) {
+    auto chunk_db = [&](auto chk, auto gmc, int it) __attribute__((always_inline)) {
         const int kc = k0 + it * C::KB;
         const int buf = it & 1;
         const bool more = (it + 1) < nchunks;
@@ -632,7 +650,7 @@ void qgemm_kernel(const GemmParams p) {
             for (int c = 0; c < CP; ++c) {
                 const wreg_t w = wcur[c];
                 wcur[c] = load_w_ring(kc + C::KB, c);
-                step(chk, buf, kc, c, w);
+                step(chk, gmc, buf, kc, c, c, w);
             }
             if (more) store_x(buf ^ 1, kc + C::KB);
         } else {
@@ -642,7 +660,7 @@ void qgemm_kernel(const GemmParams p) {
                 load_x(TrueT{}, kc + C::KB);
             }
 #pragma unroll
-            for (int c = 0; c < CP; ++c) step(chk, buf, kc, c, wcur[c]);
+            for (int c = 0; c < CP; ++c) step(chk, gmc, buf, kc, c, c, wcur[c]);
             if (more) {
                 store_x(buf ^ 1, kc + C::KB);
 #pragma unroll
@@ -653,8 +671,10 @@ void qgemm_kernel(const GemmParams p) {
     };
     // DEEP: chunk `it` (parity PAR) computes from LDS buffer PAR and weight set PAR, requests chunk it + 2 into the
     // registers it frees, and ends by writing chunk it + 1 (requested during chunk it - 1) to the other LDS buffer
-    auto chunk_deep = [&](auto chk, auto par, int it) {
+    auto chunk_deep = [&](auto chk, auto gsel, auto par, int it) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
+        // (group mode of the steps: whole groups per chunk part, or - 64-k chunks - the half this chunk is)
+        using GMC = std::integral_constant<int, !decltype(gsel)::value ? 0 : (CP % 4 == 0) ? 1 : 2 + PAR>;
         const int kc = k0 + it * C::KB;
         wreg_t* wset = PAR ? wcur2 : wcur;
         if (it + 2 < nchunks) load_x_to(TrueT{}, kc + 2 * C::KB, PAR ? sreg2 : sreg);
@@ -662,12 +682,12 @@ void qgemm_kernel(const GemmParams p) {
         for (int c = 0; c < CP; ++c) {
             const wreg_t w = wset[c];
             wset[c] = load_w_ring(kc + 2 * C::KB, c);
-            step(chk, PAR, kc, c, w);
+            step(chk, GMC{}, PAR, kc, c, c, w);
         }
         if (it + 1 < nchunks) store_x_from(PAR ^ 1, PAR ? sreg : sreg2);
         __syncthreads();
     };
-    auto chunk_sb = [&](auto chk, int it) {
+    auto chunk_sb = [&](auto chk, auto gmc, int it) __attribute__((always_inline)) {
         const int kc = k0 + it * C::KB;
         // activations first: the wait counter is positional, so staging them must not wait for the (slower,
         // HBM) weight loads issued behind them
@@ -681,7 +701,7 @@ void qgemm_kernel(const GemmParams p) {
             for (int j = 0; j < D; ++j) {
                 const wreg_t w = wcur[j];
                 if (c0 + D + j < CP) wcur[j] = load_w1(chk, kc, c0 + D + j);
-                step(chk, 0, kc, c0 + j, w);
+                step(chk, gmc, 0, kc, c0 + j, j, w);                  // (c0 is a multiple of D = 4 or 8)
             }
         }
         __syncthreads();
@@ -689,6 +709,10 @@ void qgemm_kernel(const GemmParams p) {
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    // gsel = 1: the group-aligned form of the steps (see step); one copy of the loops per form, chosen once per slice
+    auto main_loop = [&](auto gsel) __attribute__((always_inline)) {
+    constexpr bool GS = decltype(gsel)::value != 0;
+    using GM1 = std::integral_constant<int, GS ? 1 : 0>;           // (the non-DEEP loops: whole groups per chunk part)
     if constexpr (DEEP) {
         if (nchunks > 0) {
             load_x_to(TrueT{}, k0, sreg);                         // (before the weights: positional wait counter)
@@ -705,14 +729,14 @@ void qgemm_kernel(const GemmParams p) {
         const int nfull = (kend - k0) / C::KB;
         int it = 0;
         for (; it + 1 < nfull; it += 2) {
-            chunk_deep(FalseT{}, I0{}, it);
-            chunk_deep(FalseT{}, I1{}, it + 1);
+            chunk_deep(FalseT{}, gsel, I0{}, it);
+            chunk_deep(FalseT{}, gsel, I1{}, it + 1);
         }
         if (it < nfull) {
-            chunk_deep(FalseT{}, I0{}, it);
-            if (it + 1 < nchunks) chunk_deep(TrueT{}, I1{}, it + 1);
+            chunk_deep(FalseT{}, gsel, I0{}, it);
+            if (it + 1 < nchunks) chunk_deep(TrueT{}, gsel, I1{}, it + 1);
         } else if (it < nchunks) {
-            chunk_deep(TrueT{}, I0{}, it);
+            chunk_deep(TrueT{}, gsel, I0{}, it);
         }
     } else if constexpr (DB) {
         // LDS double buffer for x, register double buffer for the weights
@@ -727,16 +751,28 @@ void qgemm_kernel(const GemmParams p) {
         // the accumulators get a second home, which costs the large tiles 60-150 registers or spills)
         const int nfull = (kend - k0) / C::KB;
         int it = 0;
-        for (; it < nfull; ++it) chunk_db(FalseT{}, it);
-        if (it < nchunks) chunk_db(TrueT{}, it);
+        for (; it < nfull; ++it) chunk_db(FalseT{}, GM1{}, it);
+        if (it < nchunks) chunk_db(TrueT{}, GM1{}, it);
     } else {
         // single buffer: the activation tile of the whole K slice (normally ONE chunk) is resident in
         // LDS; after the one staging barrier every wave streams its weights through a register ring
         // of D loads in flight and never synchronises with the other waves again
         for (int it = 0; it < nchunks; ++it) {
-            if (k0 + (it + 1) * C::KB <= kend) chunk_sb(FalseT{}, it);
-            else chunk_sb(TrueT{}, it);
+            if (k0 + (it + 1) * C::KB <= kend) chunk_sb(FalseT{}, GM1{}, it);
+            else chunk_sb(TrueT{}, GM1{}, it);
         }
+    }
+    };
+    // (built where a second copy of the loops costs the tile no registers: the double-buffered tiles and the one-fragment
+    // streaming tiles of up to 8 steps; the 16- and 32-step tiles, which live at the register limit, keep one form)
+    if constexpr (GROUP && ACT == ACT_BF16 && (DB || (CP <= 8 && MT == 1)) && (CP % 4 == 0 || (CP == 2 && WK == 1 && DEEP))) {
+        // 128-k groups that the steps meet at compile-time positions (the slice must start and end on a group
+        // boundary when a chunk part is half a group; with whole groups per part it always does)
+        const bool aligned = (CP % 4 == 0) || (((k0 | (kend - k0)) & 127) == 0);
+        if (p.group == 128 && p.group_generic == 0 && aligned) main_loop(I1{});
+        else main_loop(I0{});
+    } else {
+        main_loop(I0{});
     }
 
     // ---- tail: K reduction, split-K hand-over and epilogue, spread over ALL waves of the block ----

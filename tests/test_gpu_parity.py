@@ -762,6 +762,35 @@ def test_group_sizes_unrelated_to_the_chunk_length(NQ, g, tile):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+def test_group_aligned_main_loop_bit_identical_to_generic(NQ, tmp_path):
+    """g = 128 puts the per-group kernels on the form of their main loop in which group boundaries are compile-time
+    positions of the unrolled steps (zero C operand on a group's first MFMA, no clearing of the group accumulator);
+    a second process with QL_GROUP_GENERIC=1 runs the same cases on the generic form: identical bits, every tile
+    family (double-buffered, two-chunk-deep, 64-k chunks in both halves of a group, single-buffer with staged
+    scales), K slices, the stream-K schedule and the SiLU epilogue."""
+    import os
+    import subprocess
+    import sys
+    from tests.util import group_form_outputs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "generic.pt")
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]; from tests.util import group_form_outputs; "
+            "torch.save(group_form_outputs(), %r)" % (root, os.path.join(root, "nano-vllm-hw3_amd"), out))
+    env = dict(os.environ, QL_GROUP_GENERIC="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    generic = torch.load(out)
+    fast = group_form_outputs()
+    assert set(fast) == set(generic) and len(fast) >= 120
+    for k in fast:
+        if "(4, 8, 1, 2)" in k:
+            # 64-k chunks: the generic form folds a group's sum into the total at every chunk end (twice per group,
+            # each half scaled by the group's scale), the aligned form once per group: f32 rounding apart
+            torch.testing.assert_close(fast[k].float(), generic[k].float(), rtol=2 ** -7, atol=2 ** -7, msg=k)
+        else:
+            assert torch.equal(fast[k], generic[k]), k
+
+
 # ----------------------------------------------------------------------------- fp16 / fp32 activations
 @pytest.mark.parametrize("xdt", [torch.float16, torch.float32])
 @pytest.mark.parametrize("dt", DTYPES)

@@ -71,3 +71,46 @@ def interp_f32_to_e4m3(f):
     bits = np.where(zero, sign << np.uint32(7), bits)
     valid = zero | (exp - 127 + 7 >= 1)
     return bits.astype(np.uint8), valid
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Per-group GEMM cases run twice, in two processes: on the group-aligned form of the kernels' main loop (128-k groups
+# that the unrolled steps meet at fixed positions: the first MFMA of a group takes a zero C operand) and, with
+# QL_GROUP_GENERIC=1 in the environment, on the generic form.  The two must agree bit for bit (where both fold a group's sum once).
+GROUP_FORM_TILES = [((2, 4, 2, 4), 1), ((2, 4, 2, 4), 3), ((1, 2, 4, 4), 2), ((4, 8, 1, 4), 1), ((4, 8, 1, 4), 3),
+                    ((4, 8, 1, 2), 1), ((4, 8, 1, 2), 2), ((4, 8, 1, 2), 3), ((1, 4, 2, 16), 1), ((1, 1, 8, 8), 1),
+                    ((1, 4, 1, 32), 1), ((2, 2, 4, 8), 1), ((2, 4, 1, 4), -8), ((4, 8, 1, 2), -5), (None, 0)]
+
+
+def group_form_outputs():
+    """{case name: bf16 output bits} of per-group (g = 128) W8A16 GEMMs over GROUP_FORM_TILES, both weight dtypes,
+    plain and SiLU epilogues, K with an even and an odd number of groups (a K slice of the 64-k-chunk tile may then
+    start in the middle of a group, which sends that slice to the generic form)."""
+    import torch
+    from nanovllm import _qlinear as Q
+    from nanovllm.utils import quantization as NQ
+    lib = Q.load()
+    Q.workspace.reserve("cuda", 64 << 20)
+    out = {}
+    g = torch.Generator().manual_seed(128)
+    try:
+        for (M, N, K) in ((40, 320, 1152), (200, 256, 1024), (130, 512, 2560)):
+            x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+            w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+            for dt in (torch.int8, torch.float8_e4m3fn):
+                q, s = NQ.per_group_quant(w, 128, dt)
+                qt = NQ.tile_weight(q)
+                for tile, split in GROUP_FORM_TILES:
+                    if tile is None:
+                        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+                    elif lib.ql_gemm_force_config(*tile, split) != 0:
+                        continue
+                    name = f"{M}x{N}x{K} {dt} {tile} {split}"
+                    try:
+                        out[name] = NQ.per_group_matmul(x, qt, s, None, 128, dt).cpu()
+                        out[name + " silu"] = NQ.per_group_matmul(x, qt, s, None, 128, dt, silu=True).cpu()
+                    except Q.QLinearError:
+                        pass                                  # (a split the tile's chunk does not allow for this K)
+    finally:
+        lib.ql_gemm_force_config(0, 0, 0, 0, 0)
+    return out
