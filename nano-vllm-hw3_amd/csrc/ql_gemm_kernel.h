@@ -34,6 +34,9 @@
 namespace ql {
 
 enum { ACT_BF16 = 0, ACT_I8 = 1, ACT_FP8 = 2 };
+#ifndef QL_FOLD_PK
+#define QL_FOLD_PK 1          // per-group fold on register pairs (v_pk_fma_f32); 0: one v_fma_f32 per register
+#endif
 #ifndef QL_FP8_K64
 #define QL_FP8_K64 1          // fp8 x fp8 on the K = 64 block-scaled instruction (0: the K = 16 instruction pair)
 #endif
@@ -516,6 +519,16 @@ void qgemm_kernel(const GemmParams p) {
         }
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 s2 = {s, s};
+#if !QL_FOLD_PK
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][r] = __builtin_fmaf((float)accg[i][r], s, (float)acc[i][r]);
+                if (clear) accg[i][r] = 0;
+            }
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
