@@ -68,7 +68,7 @@ int ql_quant_per_tensor(int dtype, const void* w_bf16, int64_t N, int64_t K, voi
 
 /* per_group_quant (:194-234).  scales[N, K/group] f32 = max(amax_group,1e-8)/Q; q = x/scale with
  * round-half-even + clamp (int8) or RTNE cast (fp8).  Requires group % 8 == 0 and K % group == 0 (the
- * reference: any divisor of K, :205); the GEMM below needs group % 32 == 0. */
+ * reference: any divisor of K, :205); the GEMM below takes any divisor of K (fused forms: multiples of 32). */
 int ql_quant_per_group(int dtype, const void* w_bf16, int64_t N, int64_t K, int group, void* q,
                        float* scales, void* stream);
 
@@ -108,7 +108,9 @@ size_t ql_gemm_workspace_max_bytes(int64_t max_M, int64_t N, int64_t K, int gran
  *   QL_PER_GROUP  y = bf16( bf16(sum_g sw[n,g] * sum_{k in g} x*q) + bias ) - per_group_matmul (:265-307)
  * int8/fp8 weights are widened to bf16 in registers (exact) and contracted on bf16 MFMA with f32
  * accumulation; nothing is dequantised to memory.  Requires K % 32 == 0; per-group additionally
- * group % 32 == 0 and K % group == 0 (a group's partial sum is folded with its scale at 32-k steps). */
+ * K % group == 0.  A group's partial sum is folded with its scale at 32-k steps, so group sizes that are multiples
+ * of 32 run on the MFMA kernels; any other divisor of K (the reference takes them all, :205) runs this plain form
+ * on an f32 kernel - exact per-group arithmetic, not tuned - and has none of the fused forms below (QL_ESHAPE). */
 int ql_gemm_w8a16(int wdtype, int granularity, const void* x_bf16, const void* qw, const float* sw,
                   const void* bias_bf16, void* y_bf16, int64_t M, int64_t N, int64_t K, int group,
                   void* workspace, size_t workspace_bytes, void* stream);

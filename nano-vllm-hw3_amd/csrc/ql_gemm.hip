@@ -351,6 +351,62 @@ static int run(kern_t k, GemmParams& p, const Plan& pl, void* ws, size_t ws_byte
 
 using namespace ql;
 
+namespace ql {
+// Per-group W8A16 for group sizes that are not multiples of the MFMA kernels' 32-k step (8, 16, 24, 48, ...): a plain
+// f32 kernel, 16 x 16 outputs per workgroup, operands through LDS 32 k at a time; a group's products are summed in k
+// order and folded into the total with the group's f32 scale, as in the MFMA kernels.  Correctness path for a corner
+// of the reference's interface (any divisor of K), not a tuned one.
+template <bool FP8W>
+__global__ __launch_bounds__(256) void qgemm_anygroup_kernel(const unsigned short* __restrict__ x, const unsigned char* __restrict__ w,
+                                                             const float* __restrict__ sw, const unsigned short* __restrict__ bias,
+                                                             unsigned short* __restrict__ y, int M, int N, int K, int group,
+                                                             int tiled) {
+    __shared__ float xs[16][33], ws[16][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    const int ngk = K / group, ksteps = K >> 5;
+    // staging: thread t moves x[m0 + t / 16][k0 + 2 (t % 16) .. + 1] and the same element pair of w's 16 rows
+    const int sr = threadIdx.x >> 4, sk = (threadIdx.x & 15) * 2;
+    const int xm = min((int)blockIdx.y * 16 + sr, M - 1), wn = min((int)blockIdx.x * 16 + sr, N - 1);
+    float acc = 0.f, gsum = 0.f;
+    int left = group, g = 0;
+    const int nc = min(n, N - 1);
+    float s = sw[(size_t)nc * ngk];
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + sk + e;
+            xs[sr][sk + e] = bf16_bits_to_f32(x[(size_t)xm * K + k]);
+            const size_t off = tiled ? ((((size_t)(wn >> 5) * ksteps + (k >> 5)) * 64 + (wn & 31) + 32 * ((k >> 4) & 1)) * 16 + (k & 15))
+                                     : (size_t)wn * K + k;
+            const unsigned char b = w[off];
+            ws[sr][sk + e] = FP8W ? e4m3fn_to_f32(b) : (float)(signed char)b;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < 32; ++kk) {
+            gsum = __builtin_fmaf(xs[ty][kk], ws[tx][kk], gsum);
+            if (--left == 0) {
+                acc = __builtin_fmaf(gsum, s, acc);
+                gsum = 0.f;
+                left = group;
+                g = min(g + 1, ngk - 1);
+                s = sw[(size_t)nc * ngk + g];
+            }
+        }
+        __syncthreads();
+    }
+    if (m < M && n < N) {
+        // (the per-group epilogue of the MFMA kernels: round, then the bias)
+        float v = acc;
+        if (bias) v = __fadd_rn((float)(bf16_t)v, bf16_bits_to_f32(bias[n]));
+        y[(size_t)m * N + n] = __builtin_bit_cast(unsigned short, (bf16_t)v);
+    }
+}
+}  // namespace ql
+
+using ql::qgemm_anygroup_kernel;
+
 extern "C" {
 
 size_t ql_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int granularity) {
@@ -502,8 +558,27 @@ static int gemm_w8a16(const char* fn, bool silu, int wdtype, int granularity, co
     if (rc) return rc;
     const bool grp = granularity == QL_PER_GROUP;
     if (grp) {
-        const bool ok = group >= 32 && group % 32 == 0 && K % group == 0;   // the kernels fold a group's sum at 32-k steps
-        if (!ok) { set_error("%s: group=%d unsupported for K=%lld", fn, group, (long long)K); return QL_ESHAPE; }
+        if (group <= 0 || K % group) { set_error("%s: group=%d does not divide K=%lld", fn, group, (long long)K); return QL_ESHAPE; }
+        if (group % 32) {
+            // the MFMA kernels fold a group's sum at 32-k steps; any other divisor of K (the reference takes them all,
+            // quantization.py:205) runs the plain GEMM on the f32 kernel below, and has no fused forms
+            if (silu || rope) {
+                set_error("%s: group=%d is not a multiple of 32: only the plain GEMM exists for it", fn, group);
+                return QL_ESHAPE;
+            }
+            if (M == 0) return QL_OK;
+            const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16));
+            if (wdtype == QL_FP8)
+                hipLaunchKernelGGL(qgemm_anygroup_kernel<true>, grid, dim3(256), 0, as_stream(stream), (const unsigned short*)x,
+                                   (const unsigned char*)qw, sw, (const unsigned short*)bias, (unsigned short*)y, (int)M, (int)N,
+                                   (int)K, group, tiled ? 1 : 0);
+            else
+                hipLaunchKernelGGL(qgemm_anygroup_kernel<false>, grid, dim3(256), 0, as_stream(stream), (const unsigned short*)x,
+                                   (const unsigned char*)qw, sw, (const unsigned short*)bias, (unsigned short*)y, (int)M, (int)N,
+                                   (int)K, group, tiled ? 1 : 0);
+            QL_CHECK_LAUNCH(fn);
+            return QL_OK;
+        }
     }
     if (M == 0) return QL_OK;
     GemmParams p{};

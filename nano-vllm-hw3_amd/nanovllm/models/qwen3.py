@@ -190,7 +190,8 @@ class Qwen3Attention(nn.Module):
         ctx = get_context()
         qw = self.q_norm.weight if not self.qkv_bias else None
         kw = self.k_norm.weight if not self.qkv_bias else None
-        if FUSE_QKV_ROPE and hasattr(self.qkv_proj, "qw") and self.head_dim == 128 and self.qkv_proj.qw.shape[1] % 32 == 0:
+        if (FUSE_QKV_ROPE and hasattr(self.qkv_proj, "qw") and self.head_dim == 128 and self.qkv_proj.qw.shape[1] % 32 == 0
+                and self.qkv_proj.fusable):
             # quantized qkv projection: q/k norm + RoPE + KV-cache store run in the GEMM's epilogue (one launch)
             from nanovllm.utils.quantization import qkv_rope_matmul
             rows = ctx.cos_sin_rows

@@ -570,13 +570,19 @@ class _QBase(torch.nn.Module):
             # W8A8: quantize the activations (their own launch), then the deferred form where it pays
             return self.forward_partial_quantized(*per_row_quant(x.contiguous(), self.dtype))
         if (DEFER_SPLITK and weight_only and not self.silu_fused and not (self.tp_dim == 1 and self.tp_size > 1)
-                and 0 < m <= self.PARTIAL_MAX_ROWS and x.dim() == 2):
+                and 0 < m <= self.PARTIAL_MAX_ROWS and x.dim() == 2 and self.fusable):
             gran = Q.QL_PER_GROUP if isinstance(self, QGroupLinear) else Q.QL_PER_TENSOR if isinstance(self, QTensorLinear) else Q.QL_PER_ROW
             if Q.load().ql_gemm_partial_slices(m, self.qw.shape[0], self.qw.shape[1], gran) > 1:   # else: nothing to defer
                 return w8a16_partial_matmul(self, x)
         return self(x)
 
     _defer_reduce = False
+
+    @property
+    def fusable(self):
+        """The fused forms (SiLU / qkv epilogues, deferred K slices) exist for this module's arithmetic: everything but
+        per-group scales whose group size is not a multiple of the MFMA kernels' 32-k step (plain GEMM only)."""
+        return getattr(self, "group_size", 32) % 32 == 0
 
     def _tp_partial(self, x, run=None):
         """A row-parallel shard under TP with a decode-sized input and the one-shot all-reduce switched on
@@ -828,7 +834,7 @@ def _replace(model, make, fuse_silu=True):
         l.self_attn.qkv_proj = make(l.self_attn.qkv_proj)
         l.self_attn.o_proj = make(l.self_attn.o_proj)
         l.mlp.gate_up_proj = make(l.mlp.gate_up_proj)
-        if fuse_silu and (l.mlp.gate_up_proj.qw.shape[0] // 2) % 32 == 0:
+        if fuse_silu and (l.mlp.gate_up_proj.qw.shape[0] // 2) % 32 == 0 and l.mlp.gate_up_proj.fusable:
             l.mlp.gate_up_proj.enable_silu_mul()
         l.mlp.down_proj = make(l.mlp.down_proj)
         for m in (l.self_attn.qkv_proj, l.self_attn.o_proj, l.mlp.gate_up_proj, l.mlp.down_proj):

@@ -49,7 +49,10 @@ def test_argument_validation_needs_no_gpu():
     assert b"multiple of 32" in lib.ql_last_error()
     assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 256, 96, None, 0, None) == -2    # K % group
     assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 240, 48, None, 0, None) == -2    # K % 32
-    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 192, 48, None, 0, None) == -2    # group % 32
+    # (a group size that is not a multiple of 32 is valid for the plain GEMM; its fused forms do not exist)
+    assert lib.ql_gemm_w8a16_silu(0, 2, one, one, one, None, one, 4, 64, 192, 48, None, 0, None) == -2
+    assert b"multiple of 32" in lib.ql_last_error()
+    assert lib.ql_gemm_w8a16(0, 2, one, one, one, None, one, 4, 64, 192, 0, None, 0, None) == -2     # group <= 0
     assert lib.ql_quant_per_group(0, one, 4, 256, 96, one, one, None) == -2
     assert lib.ql_quant_per_row(0, one, 4, 100, one, one, None) == -2
     assert lib.ql_gemm_w8a8(0, one, one, one, None, None, one, 4, 64, 128, None, 0, None) == -1

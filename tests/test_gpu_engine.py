@@ -400,6 +400,7 @@ def test_engine_bf16_eager_matches_torch_reference_and_graph(tiny_dir):
     dict(quant_type="per_row", linear_dtype=torch.int8),
     dict(quant_type="per_row", linear_dtype=torch.float8_e4m3fn),
     dict(quant_type="per_group", linear_dtype=torch.int8, group_size=128),
+    dict(quant_type="per_group", linear_dtype=torch.int8, group_size=16),   # below the MFMA step: plain GEMMs, no fused forms
     dict(quant_type="per_tensor", linear_dtype=torch.int8),
     dict(linear_dtype=torch.int8),   # no quant_type: non-bf16 linear dtype means per-row (model_runner.py:55-57)
 ])

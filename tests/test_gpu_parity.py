@@ -762,6 +762,32 @@ def test_group_sizes_unrelated_to_the_chunk_length(NQ, g, tile):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
+@pytest.mark.parametrize("g", [8, 16, 24, 48, 80, 120, 240])
+def test_group_sizes_that_are_not_multiples_of_32(NQ, g):
+    """The reference takes any divisor of K as the group size (quantization.py:205); sizes that are not multiples of
+    the MFMA kernels' 32-k step run the plain GEMM on the library's f32 kernel: quantizer bit-exact, GEMM at the usual
+    bar, ragged M and N, bias, row-major and tiled weights; the fused forms do not exist for them and say so."""
+    from nanovllm import _qlinear as Q
+    M, N, K = 37, 50, 960
+    rng = np.random.default_rng(1000 + g)
+    xb, wb, bb = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.05), rand_bf16(rng, (N,), 0.5)
+    for dt in DTYPES:
+        qo, so = O.per_group_quant(wb, g, dt)
+        q, s = NQ.per_group_quant(bf16_t(wb), g, TDT[dt])
+        assert np.array_equal(bits8(q), qo.view(np.uint8)) and np.array_equal(s.cpu().numpy(), so)
+        deq = (O._decode_q(qo, dt).reshape(N, -1, g) * so[..., None]).reshape(N, -1)
+        y = NQ.per_group_matmul(bf16_t(xb), q, s, None, g, TDT[dt])
+        assert_gemm_close(bits16(y), O.per_group_matmul(xb, qo, so, None, g, dt, return_f64=True),
+                          O.abs_product_sum(xb, deq), what=f"g{g} {dt}")
+        assert torch.equal(NQ.per_group_matmul(bf16_t(xb), NQ.tile_weight(q), s, None, g, TDT[dt]), y)
+        # bias: added to the ROUNDED sum (quantization.py:302-305), one more rounding
+        yb = NQ.per_group_matmul(bf16_t(xb), q, s, bf16_t(bb), g, TDT[dt])
+        assert torch.equal(yb, (y.float() + bf16_t(bb).float()[None, :]).to(torch.bfloat16))
+        with pytest.raises(Q.QLinearError, match="multiple of 32"):
+            q64, s64 = NQ.per_group_quant(bf16_t(rand_bf16(rng, (64, K), 0.05)), g, TDT[dt])
+            NQ.per_group_matmul(bf16_t(xb), q64, s64, None, g, TDT[dt], silu=True)
+
+
 def test_group_aligned_main_loop_bit_identical_to_generic(NQ, tmp_path):
     """g = 128 puts the per-group kernels on the form of their main loop in which group boundaries are compile-time
     positions of the unrolled steps (zero C operand on a group's first MFMA, no clearing of the group accumulator);
