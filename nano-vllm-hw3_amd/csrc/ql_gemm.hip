@@ -814,7 +814,7 @@ int ql_gemm_w8a8_dynq(int dtype, const void* x, const float* rowmax_part, int np
 static Plan make_plan_head(int64_t M, int64_t V, int64_t K) {
     Plan pl;
     // (129..256 rows: one row tile of as many 32-row fragments as the rows fill, 5..8)
-    int mt = M <= 32 ? 1 : M <= 64 ? 2 : M <= 128 ? 4 : M <= 256 ? (int)((M + 31) / 32) : 4, wn = M <= 128 ? 4 : 8, wk = 1,
+    int mt = M <= 32 ? 1 : M <= 64 ? 2 : M <= 128 ? 4 : M <= 256 ? (int)((M + 31) / 32) : 4, wn = M <= 160 ? 4 : 8, wk = 1,
         cp = (M > 224 && M <= 256) ? 2 : 4;
     pl.pair_rows = true;
     if (f_mt > 0 && f_wn > 0 && f_wk > 0 && f_cp > 0 && pick_head(f_mt, f_wn, f_wk, f_cp, false)) {

@@ -1124,9 +1124,10 @@ struct TileCfg { int mt, wn, wk, cp, db; };
 
 // one translation unit per arithmetic variant instantiates these
 // The output projection (bf16 weights shared with the embedding table, vocabulary-sized N, M = sequences of a step)
-// (129..224 rows: 160-, 192- and 224-row tiles, so that a step's sequences cost the MFMAs of the row fragments they fill)
+// (129..224 rows: 160-, 192- and 224-row tiles, so that a step's sequences cost the MFMAs of the row fragments they fill;
+// the 160-row tile also as a 4-wave, 128-column workgroup, two of which share a CU: the faster form up to 160 rows)
 #define QL_TILE_LIST_HEAD(X) X(1, 4, 1, 4, true) X(2, 4, 1, 4, true) X(4, 4, 1, 4, true) X(4, 8, 1, 4, true) X(8, 8, 1, 2, true) \
-    X(5, 8, 1, 4, true) X(6, 8, 1, 4, true) X(7, 8, 1, 4, true)
+    X(5, 8, 1, 4, true) X(6, 8, 1, 4, true) X(7, 8, 1, 4, true) X(5, 4, 1, 4, true)
 template <bool AMAX>
 kern_t pick_head_impl(int mt, int wn, int wk, int cp) {
 #define QL_PICK_HEAD(MT_, WN_, WK_, CP_, DB_) \

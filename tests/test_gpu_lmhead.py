@@ -16,7 +16,8 @@ from tests.util import assert_gemm_close, bits16
 
 pytestmark = pytest.mark.gpu
 
-HEAD_TILES = [(1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (4, 8, 1, 4), (8, 8, 1, 2)]    # QL_TILE_LIST_HEAD
+HEAD_TILES = [(1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (4, 8, 1, 4), (8, 8, 1, 2), (5, 8, 1, 4), (6, 8, 1, 4), (7, 8, 1, 4),
+              (5, 4, 1, 4)]    # QL_TILE_LIST_HEAD
 
 
 def _ops():

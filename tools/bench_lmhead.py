@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from nanovllm import _qlinear as Q, ops  # noqa: E402
 import bench_kernels as BK  # noqa: E402
 
-TILES = [(1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (4, 8, 1, 4), (5, 8, 1, 4), (6, 8, 1, 4), (7, 8, 1, 4), (8, 8, 1, 2)]
+TILES = [(1, 4, 1, 4), (2, 4, 1, 4), (4, 4, 1, 4), (4, 8, 1, 4), (5, 8, 1, 4), (6, 8, 1, 4), (7, 8, 1, 4), (8, 8, 1, 2), (5, 4, 1, 4)]
 
 
 def main():
