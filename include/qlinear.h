@@ -67,8 +67,9 @@ int ql_quant_per_tensor(int dtype, const void* w_bf16, int64_t N, int64_t K, voi
                         void* workspace, void* stream);
 
 /* per_group_quant (:194-234).  scales[N, K/group] f32 = max(amax_group,1e-8)/Q; q = x/scale with
- * round-half-even + clamp (int8) or RTNE cast (fp8).  Requires group % 8 == 0 and K % group == 0 (the
- * reference: any divisor of K, :205); the GEMM below takes any divisor of K (fused forms: multiples of 32). */
+ * round-half-even + clamp (int8) or RTNE cast (fp8).  Any group size that divides K, as the reference (:205):
+ * multiples of 8 on the vector kernels, other sizes one thread per group.  The GEMM below likewise takes any divisor
+ * of K (fused forms: multiples of 32). */
 int ql_quant_per_group(int dtype, const void* w_bf16, int64_t N, int64_t K, int group, void* q,
                        float* scales, void* stream);
 

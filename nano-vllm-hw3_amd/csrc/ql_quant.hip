@@ -286,8 +286,35 @@ __global__ __launch_bounds__(256) void per_group_wave_kernel(const unsigned shor
     }
 }
 
+// group sizes that are not multiples of 8 (the reference takes any divisor of K, quantization.py:205): one thread per
+// group, element by element; the same arithmetic once more
+template <int DT, bool FAKE>
+__global__ __launch_bounds__(256) void per_group_scalar_kernel(const unsigned short* __restrict__ x,
+                                                               unsigned char* __restrict__ q, float* __restrict__ scales,
+                                                               unsigned short* __restrict__ out, int64_t ngroups, int group) {
+    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * 256) {
+        const unsigned short* xg = x + gi * group;
+        float m = 0.f;
+        for (int j = 0; j < group; ++j) m = fmaxf(m, fabsf(bf16_bits_to_f32(xg[j])));
+        if (FAKE) {
+            m = fmaxf(m, round_to_bf16(1e-8f));
+            for (int j = 0; j < group; ++j) out[gi * group + j] = fake_one<DT>(bf16_bits_to_f32(xg[j]), m);
+        } else {
+            const float sc = fmaxf(m, 1e-8f) / QMax<DT>::v;
+            scales[gi] = sc;
+            for (int j = 0; j < group; ++j) {
+                const float y = bf16_bits_to_f32(xg[j]) / sc;
+                unsigned b;
+                if (DT == QL_INT8) b = (unsigned)(unsigned char)(signed char)(int)fminf(fmaxf(rintf(y), -128.f), 127.f);
+                else b = f32_to_e4m3fn(y);
+                q[gi * group + j] = (unsigned char)b;
+            }
+        }
+    }
+}
+
 static bool group_pow2(int g) { return g >= 8 && g <= 512 && (g % 8) == 0 && (512 % g) == 0; }   // shuffle kernels
-static bool group_ok(int g) { return g >= 8 && (g % 8) == 0; }
+static bool group_ok(int g) { return g >= 1; }
 static int stream_grid(int64_t total) {
     int64_t b = (total / 8 + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -378,12 +405,24 @@ int ql_quant_per_group(int dtype, const void* w, int64_t N, int64_t K, int group
         return QL_EINVAL;
     }
     if (!group_ok(group) || K % group) {
-        set_error("ql_quant_per_group: K=%lld, group=%d unsupported (need group%%8==0 and K%%group==0)",
+        set_error("ql_quant_per_group: K=%lld, group=%d unsupported (need group >= 1 and K%%group==0)",
                   (long long)K, group);
         return QL_ESHAPE;
     }
     const int64_t total = N * K;
     if (total == 0) return QL_OK;
+    if (group % 8) {
+        const int64_t ngroups = total / group;
+        dim3 grid((unsigned)((ngroups + 255) / 256 > 4096 ? 4096 : (ngroups + 255) / 256)), block(256);
+        if (dtype == QL_INT8)
+            hipLaunchKernelGGL((per_group_scalar_kernel<QL_INT8, false>), grid, block, 0, as_stream(stream),
+                               (const unsigned short*)w, (unsigned char*)q, scales, (unsigned short*)nullptr, ngroups, group);
+        else
+            hipLaunchKernelGGL((per_group_scalar_kernel<QL_FP8, false>), grid, block, 0, as_stream(stream),
+                               (const unsigned short*)w, (unsigned char*)q, scales, (unsigned short*)nullptr, ngroups, group);
+        QL_CHECK_LAUNCH("ql_quant_per_group");
+        return QL_OK;
+    }
     if (!group_pow2(group)) {
         const int64_t ngroups = total / group;
         dim3 grid((unsigned)((ngroups + 3) / 4 > 8192 ? 8192 : (ngroups + 3) / 4)), block(256);
@@ -452,7 +491,13 @@ int ql_fake_quant(int dtype, int granularity, const void* w, int64_t N, int64_t 
         const int64_t blocks = (total / 8 + 255) / 256;
         if (blocks > 0x7FFFFFFF) { set_error("ql_fake_quant: tensor too large"); return QL_ESHAPE; }
         dim3 grid((unsigned)blocks), block(256);
-        if (!group_pow2(group)) {
+        if (group % 8) {
+            const int64_t ngroups = total / group;
+            dim3 sgrid((unsigned)((ngroups + 255) / 256 > 4096 ? 4096 : (ngroups + 255) / 256));
+            if (dtype == QL_INT8) hipLaunchKernelGGL((per_group_scalar_kernel<QL_INT8, true>), sgrid, block, 0, s, x, (unsigned char*)nullptr, (float*)nullptr, o, ngroups, group);
+            else hipLaunchKernelGGL((per_group_scalar_kernel<QL_FP8, true>), sgrid, block, 0, s, x, (unsigned char*)nullptr, (float*)nullptr, o, ngroups, group);
+        }
+        else if (!group_pow2(group)) {
             const int64_t ngroups = total / group;
             dim3 wgrid((unsigned)((ngroups + 3) / 4 > 8192 ? 8192 : (ngroups + 3) / 4));
             if (dtype == QL_INT8) hipLaunchKernelGGL((per_group_wave_kernel<QL_INT8, true>), wgrid, block, 0, s, x, (unsigned char*)nullptr, (float*)nullptr, o, ngroups, group);

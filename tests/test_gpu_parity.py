@@ -762,10 +762,11 @@ def test_group_sizes_unrelated_to_the_chunk_length(NQ, g, tile):
         lib.ql_gemm_force_config(0, 0, 0, 0, 0)
 
 
-@pytest.mark.parametrize("g", [8, 16, 24, 48, 80, 120, 240])
+@pytest.mark.parametrize("g", [1, 4, 12, 20, 8, 16, 24, 48, 80, 120, 240])
 def test_group_sizes_that_are_not_multiples_of_32(NQ, g):
     """The reference takes any divisor of K as the group size (quantization.py:205); sizes that are not multiples of
-    the MFMA kernels' 32-k step run the plain GEMM on the library's f32 kernel: quantizer bit-exact, GEMM at the usual
+    the MFMA kernels' 32-k step run the plain GEMM on the library's f32 kernel (and, when not multiples of 8, the
+    quantizers on a thread-per-group kernel): quantizer and fake quantizer bit-exact, GEMM at the usual
     bar, ragged M and N, bias, row-major and tiled weights; the fused forms do not exist for them and say so."""
     from nanovllm import _qlinear as Q
     M, N, K = 37, 50, 960
@@ -775,6 +776,7 @@ def test_group_sizes_that_are_not_multiples_of_32(NQ, g):
         qo, so = O.per_group_quant(wb, g, dt)
         q, s = NQ.per_group_quant(bf16_t(wb), g, TDT[dt])
         assert np.array_equal(bits8(q), qo.view(np.uint8)) and np.array_equal(s.cpu().numpy(), so)
+        assert np.array_equal(bits16(NQ.fake_per_group_quant(bf16_t(wb), g, TDT[dt])), O.fake_per_group_quant(wb, g, dt))
         deq = (O._decode_q(qo, dt).reshape(N, -1, g) * so[..., None]).reshape(N, -1)
         y = NQ.per_group_matmul(bf16_t(xb), q, s, None, g, TDT[dt])
         assert_gemm_close(bits16(y), O.per_group_matmul(xb, qo, so, None, g, dt, return_f64=True),
